@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the UNMODIFIED reference scripts in the build container.
+
+TEST INFRASTRUCTURE.  Runs only where /root/reference exists (never on the GPU box); what it
+writes are data fixtures (inputs and expected outputs), no reference source.
+
+How the scripts are run (they are not importable: the file names are not identifiers and they
+execute the whole experiment at module level, S4:176-202):
+  * ``runpy.run_path(<script>)`` with ``sys.path[0] = /root/reference`` and cwd = a scratch dir
+    holding symlinks ``CS_MRI``, ``testsets/Set1 -> testsets/set1`` (the code asks for 'Set1',
+    S4:44) and a writable ``results/``;
+  * two modules the image lacks are provided as import shims for the I/O edge only:
+    ``torchvision.utils.make_grid`` (never called) and ``cv2`` with ``imread(path, 0)`` = PIL
+    decode + OpenCV's fixed-point gray formula, ``imwrite``, ``getGaussianKernel`` and
+    ``filter2D`` (SSIM only; utils/utils_image.py:593-615).  None of them touches the ADMM loop.
+  * x after n iterations is obtained by running the script with ``--iter_num n`` (argparse is
+    the reference's own, S4:21-29); other masks by calling the script's own solver function from
+    the globals ``run_path`` returns.
+
+Known answers this must reproduce (and does; see tests/golden/known_answers.json):
+  results/Set1_dn_ADMM_L1/Set1_dn_ADMM_L1.log:284,287-288   PSNR 23.8683 / SSIM 0.5877 / RE 0.2028
+  results/Set1_dn_ADMM_CNC/Set1_dn_ADMM_CNC.log:399-400     PSNR 24.5765 / SSIM 0.5600 / RE 0.1870
+"""
+import io
+import json
+import logging
+import os
+import runpy
+import sys
+import tempfile
+import types
+import contextlib
+import warnings
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+S1 = os.path.join(REF, '【1】ADMM_L1.py')
+S4 = os.path.join(REF, '【4】ADMM_CNC .py')
+
+
+def install_shims():
+    from PIL import Image
+    from scipy.ndimage import correlate
+
+    cv2 = types.ModuleType('cv2')
+    cv2.IMREAD_UNCHANGED = -1
+    cv2.IMREAD_GRAYSCALE = 0
+    cv2.COLOR_GRAY2RGB = 8
+    cv2.COLOR_BGR2RGB = 4
+
+    def imread(path, flag=1):
+        im = Image.open(path)
+        if flag != 0:
+            raise NotImplementedError('only grayscale decode is needed by the solvers')
+        if im.mode in ('L', 'P', '1', 'I;16'):
+            return np.asarray(im.convert('L'))
+        rgb = np.asarray(im.convert('RGB')).astype(np.int64)      # alpha dropped, as OpenCV does
+        r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+        return ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8)
+
+    def imwrite(path, img):
+        a = np.asarray(img)
+        if a.dtype != np.uint8:
+            a = np.clip(np.rint(a), 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(path)
+        return True
+
+    def getGaussianKernel(n, sigma):
+        g = np.exp(-((np.arange(n) - (n - 1) / 2.0) ** 2) / (2 * sigma ** 2))
+        return (g / g.sum()).reshape(-1, 1)
+
+    def filter2D(img, ddepth, kernel):
+        return correlate(img, kernel, mode='mirror')
+
+    cv2.imread, cv2.imwrite = imread, imwrite
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    sys.modules['cv2'] = cv2
+
+    tv = types.ModuleType('torchvision')
+    tvu = types.ModuleType('torchvision.utils')
+    tvu.make_grid = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    tv.utils = tvu
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.utils'] = tvu
+    return cv2
+
+
+def scratch_dir():
+    d = tempfile.mkdtemp(prefix='pnp_golden_')
+    os.symlink(os.path.join(REF, 'CS_MRI'), os.path.join(d, 'CS_MRI'))
+    os.makedirs(os.path.join(d, 'testsets'))
+    os.symlink(os.path.join(REF, 'testsets', 'set1'), os.path.join(d, 'testsets', 'Set1'))
+    os.makedirs(os.path.join(d, 'results'))
+    return d
+
+
+class _Capture:
+    """Reads the lines the reference's own logger appends to results/<name>/<name>.log
+    (utils/utils_logger.py:25-44) between construction and ``.lines``."""
+
+    def __init__(self, logger_name):
+        self.path = os.path.join('results', logger_name, logger_name + '.log')
+        self.start = os.path.getsize(self.path) if os.path.exists(self.path) else 0
+
+    @property
+    def lines(self):
+        for h in logging.getLogger(os.path.basename(os.path.dirname(self.path))).handlers:
+            h.flush()
+        with open(self.path) as f:
+            f.seek(self.start)
+            return [l.split(' : ', 1)[-1].rstrip('\n') for l in f.readlines()]
+
+
+def run_script(script, argv, logger_name):
+    """-> (globals of the finished script, captured logger lines, stdout)"""
+    cap = _Capture(logger_name)
+    old_argv, old_path0 = sys.argv, sys.path[0]
+    sys.argv = [script] + argv
+    sys.path.insert(0, REF)
+    out = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(out):
+            g = runpy.run_path(script, run_name='__ref__')
+    finally:
+        sys.argv = old_argv
+        sys.path.remove(REF)
+    return g, cap.lines, out.getvalue()
+
+
+def main():
+    cv2 = install_shims()
+    os.makedirs(GOLD, exist_ok=True)
+    d = scratch_dir()
+    os.chdir(d)
+    import scipy.io as sio
+
+    # ---------------- inputs (data the reference ships; repacked, not source) ----------------
+    gray = cv2.imread(os.path.join(REF, 'testsets', 'set1', '05.png'), 0)
+    noises = sio.loadmat(os.path.join(REF, 'CS_MRI', 'noises.mat'))['noises'].astype(np.complex128)
+    masks = {}
+    for name in ('Q_Random30', 'Q_Radial30', 'Q_Cartesian30'):
+        q1 = sio.loadmat(os.path.join(REF, 'CS_MRI', name + '.mat'))['Q1']
+        assert q1.shape == (256, 256) and set(np.unique(q1)) <= {0, 1}
+        masks[name] = np.packbits(q1.astype(np.uint8), axis=None)
+    np.savez_compressed(os.path.join(GOLD, 'inputs_set1_05.npz'),
+                        gray_u8=gray, noises_c128=noises,
+                        **{k + '_packbits': v for k, v in masks.items()})
+
+    known = {'numpy': np.__version__, 'note': 'produced by oracle/make_golden.py from the unmodified reference scripts'}
+    arrays = {}
+
+    # ---------------- ADMM_L1 (S1) and ADMM_CNC (S4), committed defaults, Q_Random30 ----------
+    for tag, script, lname in (('l1', S1, 'Set1_dn_ADMM_L1'), ('cnc', S4, 'Set1_dn_ADMM_CNC')):
+        for n in (1, 2, 5, 10, 50):
+            g, lines, stdout = run_script(script, ['--iter_num', str(n)], lname)
+            x = np.asarray(g['out'][0])
+            assert x.dtype == np.float64 and x.shape == (256, 256)
+            arrays['%s_random30_it%d' % (tag, n)] = x if n == 50 else x.astype(np.float32)
+            if n == 50:
+                known[tag] = {
+                    'log_line': [l for l in lines if 'PSNR' in l and '05.png' in l][0],
+                    'avg_line': [l for l in lines if 'Average' in l][0],
+                    'stdout': stdout.strip().splitlines(),
+                    'x_min': float(x.min()), 'x_max': float(x.max()), 'x_sum': float(x.sum()),
+                }
+                # other masks: the script's own solver function, its own mask/noise arrays
+                fn = g['ADMM_L1'] if tag == 'l1' else g['ADMM_CNC']
+                opts = g['ADMM_L1_opts'] if tag == 'l1' else g['ADMM_CNC_opts']
+                for k, mname in ((1, 'radial30'), (2, 'cartesian30')):
+                    cap = _Capture(lname)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        o = fn(g['mask'][k], g['noises'], **opts)
+                    arrays['%s_%s_it50' % (tag, mname)] = np.asarray(o[0]).astype(np.float32)
+                    known['%s_%s' % (tag, mname)] = {
+                        'log_line': [l for l in cap.lines if 'PSNR' in l and '05.png' in l][0],
+                        'x_sum': float(np.asarray(o[0]).sum())}
+
+    # ---------------- sigma schedule (pure NumPy module, imports as-is) -----------------------
+    sys.path.insert(0, REF)
+    from utils import utils_pnp as ref_pnp
+    rhos, sigmas = ref_pnp.get_rho_sigma(sigma=max(0.255 / 255., 15 / 255.), iter_num=50,
+                                         modelSigma1=49, modelSigma2=15, w=1.0)
+    arrays['rho_sigma_rhos'] = np.asarray(rhos, dtype=np.float64)
+    arrays['rho_sigma_sigmas'] = np.asarray(sigmas)
+    rhos1, sigmas1 = ref_pnp.get_rho_sigma1(sigma=2.55 / 255, iter_num=15, modelSigma1=49.0,
+                                            modelSigma2=2.55, lamda=3.0)
+    arrays['rho_sigma1_rhos'] = np.asarray(rhos1, dtype=np.float64)
+    arrays['rho_sigma1_sigmas'] = np.asarray(sigmas1)
+    sys.path.remove(REF)
+
+    np.savez_compressed(os.path.join(GOLD, 'admm_set1_05.npz'), **arrays)
+    with open(os.path.join(GOLD, 'known_answers.json'), 'w') as f:
+        json.dump(known, f, indent=1, sort_keys=True)
+    print(json.dumps(known, indent=1, sort_keys=True))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,53 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, not silently skip: leave the tests alone.
+    pass
+
+
+@pytest.fixture(scope='session')
+def golden_inputs():
+    d = np.load(os.path.join(GOLD, 'inputs_set1_05.npz'))
+    masks = {k[:-len('_packbits')]: np.unpackbits(d[k])[:65536].reshape(256, 256)
+             for k in d.files if k.endswith('_packbits')}
+    return {'gray': d['gray_u8'], 'noises': d['noises_c128'] * 3.0, 'masks': masks}
+
+
+@pytest.fixture(scope='session')
+def golden_admm():
+    return np.load(os.path.join(GOLD, 'admm_set1_05.npz'))
+
+
+@pytest.fixture(scope='session')
+def known_answers():
+    with open(os.path.join(GOLD, 'known_answers.json')) as f:
+        return json.load(f)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
