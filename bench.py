@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ADMM iterations/s on 256x256 complex64 slices, batch = 512 per GPU
+(BASELINE.json configs[1]: ADMM_CNC, Q_Random30, S4:176 presets), synthetic inputs of
+SURVEY.md section 8(d).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one batched ADMM iteration (x-update in k-space, CNC z-update, dual update) over
+the 512 slices a GPU holds.  Slices are independent, so N GPUs hold N x 512 different slices
+(weak scaling), run without any data-path collective, and one RCCL gather of x at the end is
+timed separately (`gather_ms`).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `value` = 512-slice batch iterations per second summed over
+ranks = slice-iterations/s / 512.  `roofline.achieved` = 57*N_pix*B*K algorithmic bytes
+ / HIP-event time of the K iterations on the kernels' own stream.
+`cpu_baseline` = the NumPy oracle (float64, np.fft, 1 thread) on a bounded sample of the same
+slices, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H = W = 256
+B_PER_GPU = 512
+PRESET = dict(alpha=0.45, lambda1=0.5, reo=0.05, b=64)          # S4:176
+ALG_BYTES_PER_PIXEL = 57
+HBM_PEAK_GBS = 8000.0                                              # MI355X_MICROARCH.md
+
+
+def cpu_baseline(masks, mask_id, budget_s=20.0, iters=100):
+    """Oracle timing on this host: as many whole 100-iteration slice solves as fit the budget."""
+    from oracle import admm_oracle as O
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    t_used, n_slices = 0.0, 0
+    # one untimed warm-up slice-solve of 5 iterations (imports, pocketfft plan cache)
+    y = O.synthesize(S.phantom(0), masks[mask_id[0]].astype(np.float64), S.kspace_noise(0))
+    O.admm_cnc(y, masks[mask_id[0]], 5, **PRESET)
+    while t_used < budget_s and n_slices < B_PER_GPU:
+        b = n_slices
+        y = O.synthesize(S.phantom(b), masks[mask_id[b]].astype(np.float64), S.kspace_noise(b))
+        t0 = time.perf_counter()
+        O.admm_cnc(y, masks[mask_id[b]], iters, **PRESET)
+        t_used += time.perf_counter() - t0
+        n_slices += 1
+    slice_it_s = n_slices * iters / t_used
+    return {'value': slice_it_s / B_PER_GPU, 'unit': 'it/s (512-slice batches)', 'cores': 1, 'kind': 'port',
+            'slice_iterations_per_s': slice_it_s,
+            'sample': '%d slices x %d iterations of the same workload, %.1f s, NumPy %s float64 np.fft, 1 thread'
+                      % (n_slices, iters, t_used, np.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='slices per GPU (default 512 = the headline config)')
+    ap.add_argument('--solver', choices=['cnc', 'l1'], default='cnc')
+    ap.add_argument('--generic', action='store_true', help='force the generic (unfused) kernels')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import synthetic as S
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    B = args.batch
+    mk = S.reference_masks()
+    masks = np.stack([mk['Q_Random30']]).astype(np.uint8)            # config 2: Q_Random30 for every slice
+    mask_id = np.zeros(B, np.int32)
+    img, noise = S.batch(rank * B, B)                                 # this rank's shard of the job
+
+    eng = P.Engine(H, W, Bmax=B, device=local_rank)
+    if args.generic:
+        eng.set_fast_path(0)
+    eng.synthesize(img, noise, masks, mask_id)                        # y = fft2(img)*mask + noise, on device
+    eng.init_state()
+
+    def run(n):
+        if args.solver == 'cnc':
+            eng.admm_cnc(n, PRESET['alpha'], PRESET['lambda1'], PRESET['reo'], PRESET['b'])
+        else:
+            eng.admm_l1(n, 0.1, 0.015)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    run(args.steps)
+    ev_ms = eng.timer_stop()                                          # HIP events on the kernels' stream
+    fence()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+
+    # the one collective of the job: gather x on rank 0 over RCCL (timed apart from the steps)
+    gather_ms = None
+    x_dev = torch.empty((B, H, W), dtype=torch.float32, device='cuda')
+    eng.x(out=x_dev)
+    eng.sync()
+    if dist is not None:
+        bufs = [torch.empty_like(x_dev) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        dist.gather(x_dev, bufs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        t = torch.tensor([wall_ms, ev_ms, gather_ms], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_ms, ev_ms, gather_ms = (float(v) for v in t.cpu())
+    checksum = float(x_dev.double().sum())
+    finite = bool(torch.isfinite(x_dev).all())
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = wall_ms / K
+        value = world * K / (wall_ms * 1e-3) * (B / B_PER_GPU)
+        alg_bytes = ALG_BYTES_PER_PIXEL * H * W * B * K
+        achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')        # per-iteration HBM bytes from rocprofv3 --pmc
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(eng.path_name, {}).get('hbm_bytes_per_iteration_b512')
+                if traffic is not None and B != B_PER_GPU:
+                    traffic = None
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'ADMM iterations/sec on 256x256 complex64 slices (batch=512)',
+            'value': value, 'unit': 'it/s (512-slice batches)',
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ADMM_%s, %d synthetic 256x256 complex64 slices per GPU, Q_Random30, S4:176 presets'
+                                   % (args.solver.upper(), B),
+                       'slices_per_gpu': B, 'path': eng.path_name,
+                       'kernels_per_iteration': eng.kernels_per_iteration},
+            'slice_iterations_per_s': value * B_PER_GPU,
+            'hip_event_ms_per_step': ev_ms / K,
+            'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'note': 'achieved = 57*H*W*B algorithmic bytes per iteration / HIP-event time per iteration '
+                                 '(all kernels of one iteration); traffic = measured HBM bytes per iteration'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,138 @@
+/*
+ * pnp_mri.h -- C ABI of libpnpmri.so: the MI355X (gfx950) hot path of PnP-ADMM-CNC MRI
+ * reconstruction.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * What it replaces.  zj15001/PNP_ADMM_CNC_MRI has no FFI on this path: the per-iteration loop is
+ * ~15 lines of NumPy pasted inline into every solver function.  Each entry point below cites the
+ * reference lines (aliases of SURVEY.md: S1 = "【1】ADMM_L1.py", S3 = "【3】PNP_ADMM_L1_D  .py",
+ * S4 = "【4】ADMM_CNC .py", S6 = "【6】PNP_ADMM_CNC_D .py") it stands in for.  The only C-ABI
+ * precedent in the reference is BM3D's ctypes layer (bm3d307/bm3d/bm3d_py.h:4-16,
+ * bm3d_ctypes.py:194-240); INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (PNP_E_*); pnp_last_error() gives the
+ *     thread-local message.  No exceptions, no aborts.
+ *   - complex data = interleaved (re,im) float pairs ("complex64"), layout [B][H][W] row-major,
+ *     k-space in un-shifted FFT order (DC at [0,0]), forward transform unnormalised, inverse
+ *     carrying 1/(H*W) -- exactly np.fft.fft2 / np.fft.ifft2.
+ *   - "dev" pointers are device pointers borrowed from the caller (never freed by the library);
+ *     functions taking `on_device` accept either host or device memory.
+ *   - all kernels are asynchronous on the ctx stream (pnp_set_stream); only pnp_sync,
+ *     host-side downloads and pnp_timer_stop block.
+ *   - one ctx per device per host thread; a ctx is not re-entrant.
+ *   - H, W in {256, 512}.  B <= Bmax.
+ */
+#ifndef PNP_MRI_H
+#define PNP_MRI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNP_OK            0
+#define PNP_E_ARG        -1   /* bad argument (null, size, unsupported H/W) */
+#define PNP_E_HIP        -2   /* a HIP runtime call failed                  */
+#define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
+#define PNP_E_NOMEM      -4
+
+#define PNP_ABI_VERSION   1
+
+typedef struct pnp_ctx pnp_ctx;
+
+/* ---- library / context ------------------------------------------------------------------ */
+int         pnp_abi_version(void);
+const char* pnp_last_error(void);
+/* number of HIP devices visible (0 and PNP_OK when there is none). */
+int         pnp_device_count(int* n);
+
+int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out);
+int pnp_ctx_destroy(pnp_ctx* ctx);
+/* hipStream_t as void*; NULL = the default stream.  PnP solvers pass torch's current stream. */
+int pnp_set_stream(pnp_ctx* ctx, void* hip_stream);
+int pnp_sync(pnp_ctx* ctx);
+/* 0 = generic kernels only, 1 = allow the fused gfx950 kernels where shapes permit (default). */
+int pnp_set_fast_path(pnp_ctx* ctx, int enable);
+
+/* ---- problem upload ---------------------------------------------------------------------- */
+/* y: [B][H][W] complex64, the measurements  y = fft2(img)*mask + noises  (S4:102).
+ * mask_bank: [K][H][W] uint8 in {0,1}, FFT-native layout (CS_MRI/Q_*.mat variable Q1; S4:185).
+ * mask_id:   [B] int32 in [0,K): which mask each slice uses (NULL = all slices use mask 0).
+ * Replaces the per-image `y`, `index = np.nonzero(mask)` set-up of S4:101-106. */
+int pnp_upload_problem(pnp_ctx* ctx, const float* y, const uint8_t* mask_bank,
+                       const int32_t* mask_id, int B, int K, int on_device);
+
+/* On-device measurement synthesis (S4:102, "noise on all points"):
+ * y = fft2(img)*mask + noise.  img: [B][H][W] float32; noise: [B][H][W] complex64 or, with
+ * noise_per_slice = 0, one [H][W] complex64 array shared by all slices (the reference's
+ * noises.mat).  Masks as in pnp_upload_problem.  Leaves y in the ctx like pnp_upload_problem. */
+int pnp_synthesize_problem(pnp_ctx* ctx, const float* img, const float* noise, int noise_per_slice,
+                           const uint8_t* mask_bank, const int32_t* mask_id, int B, int K,
+                           int on_device);
+/* copy the ctx's y back ([B][H][W] complex64). */
+int pnp_download_y(pnp_ctx* ctx, float* y, int on_device);
+
+/* z0 = |ifft2(y)| (complex modulus), w0 = 0                                     (S4:103-109) */
+int pnp_init_state(pnp_ctx* ctx);
+/* overwrite / read the ctx-owned ADMM state z, w ([B][H][W] float32 each); NULL skips one. */
+int pnp_set_state(pnp_ctx* ctx, const float* z, const float* w, int on_device);
+int pnp_get_state(pnp_ctx* ctx, float* z, float* w, int on_device);
+
+/* ---- whole loops on the ctx-owned state (no host sync inside) ----------------------------- */
+/* ADMM_L1 main loop, S1:111-126:  x = dc(z,w); z = soft(x+w, reo*lambda1); w += x - z. */
+int pnp_admm_l1_run(pnp_ctx* ctx, int iters, float lambda1, float reo);
+/* ADMM_CNC main loop, S4:115-132: x = dc(z,w); s = soft(z,1/b);
+ * t = (1-alpha) z + alpha (x+w) + alpha*reo*lambda1*b (z-s); z = soft(t, alpha*reo*lambda1);
+ * w += x - z. */
+int pnp_admm_cnc_run(pnp_ctx* ctx, int iters, float alpha, float lambda1, float reo, float b);
+/* x of the last iteration ([B][H][W] float32) -- what the solvers return (S4:138). */
+int pnp_download_x(pnp_ctx* ctx, float* x, int on_device);
+
+/* ---- step-wise operators on caller-owned device pointers (the PnP path) ------------------- */
+/* x-update / data-consistency solve, S4:119-124 == S6:266-271:
+ *   X = fft2(z - w); X[mask] = (La2*X[mask] + y[mask])/(1+La2), La2 = 1/(2 reo);
+ *   x = |Re ifft2(X)|.      z, w, x: [B][H][W] float32 device pointers (x may alias neither). */
+int pnp_dc_step(pnp_ctx* ctx, const float* z_dev, const float* w_dev, float* x_dev, float reo);
+/* z = soft(x + w, thr); w = w + x - z                                           (S1:123,126) */
+int pnp_prox_l1_dual(pnp_ctx* ctx, const float* x_dev, float* z_dev, float* w_dev, float thr);
+/* CNC z-update + dual update                                                 (S4:127-129,132) */
+int pnp_prox_cnc_dual(pnp_ctx* ctx, const float* x_dev, float* z_dev, float* w_dev,
+                      float alpha, float lambda1, float reo, float b);
+/* t = (1-alpha) z + alpha (x+w) + alpha*reo*lambda1*b (z - s)                       (S6:301) */
+int pnp_cnc_combine(pnp_ctx* ctx, const float* z_dev, const float* x_dev, const float* w_dev,
+                    const float* s_dev, float* t_dev, float alpha, float lambda1, float reo, float b);
+/* t = x + w  (the denoiser input of PNP_ADMM_L1_D, S3:290) */
+int pnp_add(pnp_ctx* ctx, const float* a_dev, const float* b_dev, float* out_dev);
+/* w = w + x - z, then x,z,w <- clamp(.,0,1)                                 (S6:305-308) */
+int pnp_dual_clamp(pnp_ctx* ctx, float* x_dev, float* z_dev, float* w_dev);
+
+/* ---- operator API (batched; B slices of the ctx's H x W; complex64 device pointers) ------- */
+int pnp_fft2_fwd(pnp_ctx* ctx, const float* in_dev, float* out_dev, int B);   /* np.fft.fft2  */
+int pnp_fft2_inv(pnp_ctx* ctx, const float* in_dev, float* out_dev, int B);   /* np.fft.ifft2 */
+/* A x = fft2(x) * mask (x real [B][H][W]); uses the uploaded masks.                 (S4:102) */
+int pnp_A(pnp_ctx* ctx, const float* x_dev, float* k_dev);
+/* A^H k = ifft2(k * mask) -> complex [B][H][W]                         (utils/utils.py:54) */
+int pnp_AH(pnp_ctx* ctx, const float* k_dev, float* out_dev);
+/* Df(x, mask, y) = ifft2(mask*fft2(x) - mask*y), x real -> complex    (utils/utils.py:50-55) */
+int pnp_Df(pnp_ctx* ctx, const float* x_dev, float* out_dev);
+
+/* ---- metrics (utils/utils_image.py:543-556, 622-636), per slice -------------------------- */
+/* img_E = x*255 vs ground truth gt (uint8 [B][H][W]); writes psnr[b] (dB) and re[b].
+ * x_dev = NULL means the ctx-owned x of the last pnp_admm_*_run. */
+int pnp_metrics(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_device,
+                double* psnr_host, double* re_host);
+
+/* ---- timing on the ctx stream (HIP events) ------------------------------------------------ */
+int pnp_timer_start(pnp_ctx* ctx);
+int pnp_timer_stop(pnp_ctx* ctx, float* elapsed_ms);    /* records, synchronises, returns ms */
+
+/* ---- introspection ------------------------------------------------------------------------ */
+/* kernels launched per ADMM iteration on the current path, and which path ("generic"|"fused") */
+int         pnp_kernels_per_iteration(pnp_ctx* ctx);
+const char* pnp_path_name(pnp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNP_MRI_H */

@@ -1,0 +1,465 @@
+// C ABI of libpnpmri.so (include/pnp_mri.h): context, problem upload, whole ADMM loops, step-wise
+// operators.  Host-side only; kernels live in kernels_generic.hip / kernels_fused256.hip.
+#include "../../include/pnp_mri.h"
+#include "internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+using namespace pnp;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(PNP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct pnp_ctx {
+    int device = 0, H = 0, W = 0, Bmax = 0;
+    int B = 0, K = 0;                 // current problem (0 = none uploaded)
+    size_t N = 0;                     // H*W
+    hipStream_t stream = nullptr;
+    bool fast = true;
+    bool have_x = false;
+    float2* y = nullptr;              // [Bmax][H][W]
+    float2* work = nullptr;           // [Bmax][H][W] transform intermediate
+    float *z = nullptr, *w = nullptr, *x = nullptr;
+    uint8_t* mask_bank = nullptr;     // [Kcap][H][W]
+    int Kcap = 0;
+    int32_t* mask_id = nullptr;       // [Bmax]
+    uint8_t* gt = nullptr;            // [Bmax][H][W] (metrics, lazily)
+    double* acc = nullptr;            // [Bmax][2]
+    void* stage = nullptr;            // staging for host inputs of synthesize
+    size_t stage_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Fused256* fused = nullptr;
+    bool fused_ready = false;         // tables prepared for the current problem
+};
+
+static bool supported(int n) { return n == 256 || n == 512; }
+
+static ProxParams make_prox_l1(double lambda1, double reo) {
+    ProxParams p{};
+    p.thr = (float)(reo * lambda1);
+    return p;
+}
+static ProxParams make_prox_cnc(double alpha, double lambda1, double reo, double b) {
+    ProxParams p{};
+    p.thr = (float)(alpha * reo * lambda1);
+    p.c1 = (float)(1.0 - alpha);
+    p.c2 = (float)alpha;
+    p.c3 = (float)(alpha * reo * lambda1 * b);
+    p.ib = (float)(1.0 / b);
+    return p;
+}
+static float dc_coeff(double reo) { return (float)(1.0 / (1.0 + 1.0 / 2.0 / reo)); }
+
+static bool use_fused(pnp_ctx* c) { return c->fast && c->fused && c->fused_ready; }
+
+extern "C" {
+
+int pnp_abi_version(void) { return PNP_ABI_VERSION; }
+const char* pnp_last_error(void) { return g_err; }
+
+int pnp_device_count(int* n) {
+    if (!n) return fail(PNP_E_ARG, "pnp_device_count: null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *n = c;
+    return PNP_OK;
+}
+
+int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out) {
+    if (!out) return fail(PNP_E_ARG, "pnp_ctx_create: out is null");
+    *out = nullptr;
+    if (!supported(H) || !supported(W)) return fail(PNP_E_ARG, "pnp_ctx_create: H, W must be 256 or 512 (got %dx%d)", H, W);
+    if (Bmax < 1) return fail(PNP_E_ARG, "pnp_ctx_create: Bmax must be >= 1");
+    HIPCHK(hipSetDevice(device));
+    pnp_ctx* c = new (std::nothrow) pnp_ctx();
+    if (!c) return fail(PNP_E_NOMEM, "pnp_ctx_create: host allocation failed");
+    c->device = device; c->H = H; c->W = W; c->Bmax = Bmax; c->N = (size_t)H * W;
+    const size_t BN = (size_t)Bmax * c->N;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc((void**)&c->y, BN * sizeof(float2));
+    alloc((void**)&c->work, BN * sizeof(float2));
+    alloc((void**)&c->z, BN * sizeof(float));
+    alloc((void**)&c->w, BN * sizeof(float));
+    alloc((void**)&c->x, BN * sizeof(float));
+    alloc((void**)&c->mask_id, (size_t)Bmax * sizeof(int32_t));
+    alloc((void**)&c->acc, (size_t)Bmax * 2 * sizeof(double));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = upload_twiddles();
+    if (e != hipSuccess) {
+        pnp_ctx_destroy(c);
+        return fail(e == hipErrorOutOfMemory ? PNP_E_NOMEM : PNP_E_HIP, "pnp_ctx_create: %s", hipGetErrorString(e));
+    }
+    if (H == 256 && W == 256) {
+        hipError_t fe = hipSuccess;
+        c->fused = fused256_create(Bmax, &fe);      // null when the fused path is unavailable
+        if (!c->fused && fe != hipSuccess && fe != hipErrorNotSupported) {
+            pnp_ctx_destroy(c);
+            return fail(PNP_E_HIP, "pnp_ctx_create: fused path: %s", hipGetErrorString(fe));
+        }
+    }
+    *out = c;
+    return PNP_OK;
+}
+
+int pnp_ctx_destroy(pnp_ctx* c) {
+    if (!c) return PNP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->fused) fused256_destroy(c->fused);
+    void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return PNP_OK;
+}
+
+#define CTX(c) do { if (!(c)) return fail(PNP_E_ARG, "%s: ctx is null", __func__); HIPCHK(hipSetDevice((c)->device)); } while (0)
+#define NEED_PROBLEM(c) do { if ((c)->B <= 0) return fail(PNP_E_STATE, "%s: no problem uploaded", __func__); } while (0)
+
+int pnp_set_stream(pnp_ctx* c, void* s) { CTX(c); c->stream = (hipStream_t)s; return PNP_OK; }
+int pnp_sync(pnp_ctx* c) { CTX(c); HIPCHK(hipStreamSynchronize(c->stream)); return PNP_OK; }
+int pnp_set_fast_path(pnp_ctx* c, int enable) { CTX(c); c->fast = enable != 0; return PNP_OK; }
+
+static int copy_in(pnp_ctx* c, void* dst, const void* src, size_t bytes, int on_device) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));   // caller may reuse its host buffer
+    return PNP_OK;
+}
+static int copy_out(pnp_ctx* c, void* dst, const void* src, size_t bytes, int on_device) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));
+    return PNP_OK;
+}
+
+static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
+    if (!mask_bank) return fail(PNP_E_ARG, "mask_bank is null");
+    if (B < 1 || B > c->Bmax) return fail(PNP_E_ARG, "B=%d out of range [1,%d]", B, c->Bmax);
+    if (K < 1) return fail(PNP_E_ARG, "K must be >= 1");
+    if (K > c->Kcap) {
+        if (c->mask_bank) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->mask_bank)); c->mask_bank = nullptr; c->Kcap = 0; }
+        HIPCHK(hipMalloc((void**)&c->mask_bank, (size_t)K * c->N));
+        c->Kcap = K;
+    }
+    int rc = copy_in(c, c->mask_bank, mask_bank, (size_t)K * c->N, on_device);
+    if (rc) return rc;
+    if (mask_id) {
+        if (!on_device) for (int i = 0; i < B; ++i) if (mask_id[i] < 0 || mask_id[i] >= K) return fail(PNP_E_ARG, "mask_id[%d]=%d out of range [0,%d)", i, mask_id[i], K);
+        rc = copy_in(c, c->mask_id, mask_id, (size_t)B * sizeof(int32_t), on_device);
+        if (rc) return rc;
+    } else {
+        HIPCHK(hipMemsetAsync(c->mask_id, 0, (size_t)B * sizeof(int32_t), c->stream));
+    }
+    c->B = B; c->K = K; c->have_x = false; c->fused_ready = false;
+    return PNP_OK;
+}
+
+static int prepare_fused(pnp_ctx* c) {
+    if (c->fused) {
+        HIPCHK(fused256_prepare(c->fused, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
+        c->fused_ready = true;
+    }
+    return PNP_OK;
+}
+
+int pnp_upload_problem(pnp_ctx* c, const float* y, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
+    CTX(c);
+    if (!y) return fail(PNP_E_ARG, "pnp_upload_problem: y is null");
+    int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
+    if (rc) { c->B = 0; return rc; }
+    rc = copy_in(c, c->y, y, (size_t)B * c->N * sizeof(float2), on_device);
+    if (rc) { c->B = 0; return rc; }
+    return prepare_fused(c);
+}
+
+int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int noise_per_slice,
+                           const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
+    CTX(c);
+    if (!img || !noise) return fail(PNP_E_ARG, "pnp_synthesize_problem: img/noise is null");
+    int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
+    if (rc) { c->B = 0; return rc; }
+    const size_t img_bytes = (size_t)B * c->N * sizeof(float);
+    const size_t noise_bytes = (noise_per_slice ? (size_t)B : 1) * c->N * sizeof(float2);
+    const float* d_img = img;
+    const float2* d_noise = (const float2*)noise;
+    if (!on_device) {
+        const size_t need = img_bytes + noise_bytes;
+        if (need > c->stage_bytes) {
+            if (c->stage) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
+            HIPCHK(hipMalloc(&c->stage, need));
+            c->stage_bytes = need;
+        }
+        rc = copy_in(c, c->stage, img, img_bytes, 0); if (rc) return rc;
+        rc = copy_in(c, (char*)c->stage + img_bytes, noise, noise_bytes, 0); if (rc) return rc;
+        d_img = (const float*)c->stage;
+        d_noise = (const float2*)((char*)c->stage + img_bytes);
+    }
+    RowArgs ra{};
+    ra.rin0 = d_img; ra.cout = c->y; ra.scale = 1.0f; ra.nrows = B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_REAL, false, EPI_COMPLEX, ra));
+    ColArgs ca{};
+    ca.in = c->y; ca.out = c->y; ca.y = d_noise; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id;
+    ca.y_per_slice = noise_per_slice; ca.B = B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, true, MID_MASK_ADD, false, ca));
+    return prepare_fused(c);
+}
+
+int pnp_download_y(pnp_ctx* c, float* y, int on_device) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!y) return fail(PNP_E_ARG, "pnp_download_y: null");
+    return copy_out(c, y, c->y, (size_t)c->B * c->N * sizeof(float2), on_device);
+}
+
+int pnp_init_state(pnp_ctx* c) {
+    CTX(c); NEED_PROBLEM(c);
+    ColArgs ca{};
+    ca.in = c->y; ca.out = c->work; ca.B = c->B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, false, MID_NONE, true, ca));
+    RowArgs ra{};
+    ra.cin = c->work; ra.x_out = c->z; ra.scale = 1.0f / (float)c->N; ra.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_COMPLEX, true, EPI_ABS_COMPLEX, ra));
+    HIPCHK(hipMemsetAsync(c->w, 0, (size_t)c->B * c->N * sizeof(float), c->stream));
+    c->have_x = false;
+    return PNP_OK;
+}
+
+int pnp_set_state(pnp_ctx* c, const float* z, const float* w, int on_device) {
+    CTX(c); NEED_PROBLEM(c);
+    const size_t bytes = (size_t)c->B * c->N * sizeof(float);
+    int rc;
+    if (z) { rc = copy_in(c, c->z, z, bytes, on_device); if (rc) return rc; }
+    if (w) { rc = copy_in(c, c->w, w, bytes, on_device); if (rc) return rc; }
+    c->have_x = false;
+    return PNP_OK;
+}
+
+int pnp_get_state(pnp_ctx* c, float* z, float* w, int on_device) {
+    CTX(c); NEED_PROBLEM(c);
+    const size_t bytes = (size_t)c->B * c->N * sizeof(float);
+    int rc;
+    if (z) { rc = copy_out(c, z, c->z, bytes, on_device); if (rc) return rc; }
+    if (w) { rc = copy_out(c, w, c->w, bytes, on_device); if (rc) return rc; }
+    return PNP_OK;
+}
+
+// one generic iteration: rows fwd (z-w) -> cols fwd/blend/inv -> rows inv + prox + dual
+static int generic_iteration(pnp_ctx* c, const float* z_in, const float* w_in, RowEpi epi, const ProxParams& pp,
+                             float cdc, float* x_out, float* z_io, float* w_io) {
+    RowArgs ra{};
+    ra.rin0 = z_in; ra.rin1 = w_in; ra.cout = c->work; ra.scale = 1.0f; ra.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_REAL_DIFF, false, EPI_COMPLEX, ra));
+    ColArgs ca{};
+    ca.in = c->work; ca.out = c->work; ca.y = c->y; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id;
+    ca.c = cdc; ca.B = c->B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, true, MID_BLEND, true, ca));
+    RowArgs rb{};
+    rb.cin = c->work; rb.x_out = x_out; rb.z = z_io; rb.w = w_io; rb.scale = 1.0f / (float)c->N;
+    rb.prox = pp; rb.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_COMPLEX, true, epi, rb));
+    return PNP_OK;
+}
+
+static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, float reo) {
+    if (iters < 0) return fail(PNP_E_ARG, "iters must be >= 0");
+    if (!(reo > 0.0f)) return fail(PNP_E_ARG, "reo must be > 0");
+    if (iters == 0) return PNP_OK;
+    const float cdc = dc_coeff(reo);
+    if (use_fused(c)) {
+        HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp));
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            int rc = generic_iteration(c, c->z, c->w, cnc ? EPI_CNC : EPI_L1, pp, cdc,
+                                       (i == iters - 1) ? c->x : nullptr, c->z, c->w);
+            if (rc) return rc;
+        }
+    }
+    c->have_x = true;
+    return PNP_OK;
+}
+
+int pnp_admm_l1_run(pnp_ctx* c, int iters, float lambda1, float reo) {
+    CTX(c); NEED_PROBLEM(c);
+    return run_loop(c, iters, false, make_prox_l1(lambda1, reo), reo);
+}
+
+int pnp_admm_cnc_run(pnp_ctx* c, int iters, float alpha, float lambda1, float reo, float b) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!(b > 0.0f)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: b must be > 0");
+    return run_loop(c, iters, true, make_prox_cnc(alpha, lambda1, reo, b), reo);
+}
+
+int pnp_download_x(pnp_ctx* c, float* x, int on_device) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!x) return fail(PNP_E_ARG, "pnp_download_x: null");
+    if (!c->have_x) return fail(PNP_E_STATE, "pnp_download_x: no iteration has been run since the state was set");
+    return copy_out(c, x, c->x, (size_t)c->B * c->N * sizeof(float), on_device);
+}
+
+int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, float reo) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
+    if (!(reo > 0.0f)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
+    if (use_fused(c)) {
+        HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        return PNP_OK;
+    }
+    return generic_iteration(c, z, w, EPI_ABS_REAL, ProxParams{}, dc_coeff(reo), x, nullptr, nullptr);
+}
+
+int pnp_prox_l1_dual(pnp_ctx* c, const float* x, float* z, float* w, float thr) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_prox_l1_dual: null pointer");
+    ProxParams p{}; p.thr = thr;
+    HIPCHK(launch_prox(c->stream, false, x, z, w, p, (size_t)c->B * c->N));
+    return PNP_OK;
+}
+
+int pnp_prox_cnc_dual(pnp_ctx* c, const float* x, float* z, float* w, float alpha, float lambda1, float reo, float b) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: null pointer");
+    if (!(b > 0.0f)) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: b must be > 0");
+    HIPCHK(launch_prox(c->stream, true, x, z, w, make_prox_cnc(alpha, lambda1, reo, b), (size_t)c->B * c->N));
+    return PNP_OK;
+}
+
+int pnp_cnc_combine(pnp_ctx* c, const float* z, const float* x, const float* w, const float* s, float* t,
+                    float alpha, float lambda1, float reo, float b) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!z || !x || !w || !s || !t) return fail(PNP_E_ARG, "pnp_cnc_combine: null pointer");
+    HIPCHK(launch_combine(c->stream, z, x, w, s, t, (float)(1.0 - (double)alpha), alpha,
+                          (float)((double)alpha * reo * lambda1 * b), (size_t)c->B * c->N));
+    return PNP_OK;
+}
+
+int pnp_add(pnp_ctx* c, const float* a, const float* b, float* o) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!a || !b || !o) return fail(PNP_E_ARG, "pnp_add: null pointer");
+    HIPCHK(launch_add(c->stream, a, b, o, (size_t)c->B * c->N));
+    return PNP_OK;
+}
+
+int pnp_dual_clamp(pnp_ctx* c, float* x, float* z, float* w) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_dual_clamp: null pointer");
+    HIPCHK(launch_dual_clamp(c->stream, x, z, w, (size_t)c->B * c->N));
+    return PNP_OK;
+}
+
+static int fft2_any(pnp_ctx* c, const float* in, float* out, int B, bool inv) {
+    if (!in || !out) return fail(PNP_E_ARG, "fft2: null pointer");
+    if (B < 1 || B > c->Bmax) return fail(PNP_E_ARG, "fft2: B=%d out of range [1,%d]", B, c->Bmax);
+    RowArgs ra{};
+    ra.cin = (const float2*)in; ra.cout = (float2*)out; ra.scale = inv ? 1.0f / (float)c->N : 1.0f; ra.nrows = B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_COMPLEX, inv, EPI_COMPLEX, ra));
+    ColArgs ca{};
+    ca.in = (const float2*)out; ca.out = (float2*)out; ca.B = B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, !inv, MID_NONE, inv, ca));
+    return PNP_OK;
+}
+
+int pnp_fft2_fwd(pnp_ctx* c, const float* in, float* out, int B) { CTX(c); return fft2_any(c, in, out, B, false); }
+int pnp_fft2_inv(pnp_ctx* c, const float* in, float* out, int B) { CTX(c); return fft2_any(c, in, out, B, true); }
+
+int pnp_A(pnp_ctx* c, const float* x, float* k) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!x || !k) return fail(PNP_E_ARG, "pnp_A: null pointer");
+    RowArgs ra{};
+    ra.rin0 = x; ra.cout = (float2*)k; ra.scale = 1.0f; ra.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_REAL, false, EPI_COMPLEX, ra));
+    ColArgs ca{};
+    ca.in = (const float2*)k; ca.out = (float2*)k; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id; ca.B = c->B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, true, MID_MASK, false, ca));
+    return PNP_OK;
+}
+
+int pnp_AH(pnp_ctx* c, const float* k, float* out) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!k || !out) return fail(PNP_E_ARG, "pnp_AH: null pointer");
+    ColArgs ca{};
+    ca.in = (const float2*)k; ca.out = (float2*)out; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id; ca.B = c->B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, false, MID_MASK, true, ca));
+    RowArgs ra{};
+    ra.cin = (const float2*)out; ra.cout = (float2*)out; ra.scale = 1.0f / (float)c->N; ra.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_COMPLEX, true, EPI_COMPLEX, ra));
+    return PNP_OK;
+}
+
+int pnp_Df(pnp_ctx* c, const float* x, float* out) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!x || !out) return fail(PNP_E_ARG, "pnp_Df: null pointer");
+    RowArgs ra{};
+    ra.rin0 = x; ra.cout = (float2*)out; ra.scale = 1.0f; ra.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_REAL, false, EPI_COMPLEX, ra));
+    ColArgs ca{};
+    ca.in = (const float2*)out; ca.out = (float2*)out; ca.y = c->y; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id; ca.B = c->B;
+    HIPCHK(launch_cols(c->stream, c->H, c->W, true, MID_RESID, true, ca));
+    RowArgs rb{};
+    rb.cin = (const float2*)out; rb.cout = (float2*)out; rb.scale = 1.0f / (float)c->N; rb.nrows = c->B * c->H;
+    HIPCHK(launch_rows(c->stream, c->W, IN_COMPLEX, true, EPI_COMPLEX, rb));
+    return PNP_OK;
+}
+
+int pnp_metrics(pnp_ctx* c, const float* x, const uint8_t* gt, int gt_on_device, double* psnr, double* re) {
+    CTX(c); NEED_PROBLEM(c);
+    if (!gt || !psnr || !re) return fail(PNP_E_ARG, "pnp_metrics: null pointer");
+    if (!x) {
+        if (!c->have_x) return fail(PNP_E_STATE, "pnp_metrics: x_dev is null and the ctx holds no x yet");
+        x = c->x;
+    }
+    const uint8_t* d_gt = gt;
+    if (!gt_on_device) {
+        if (!c->gt) HIPCHK(hipMalloc((void**)&c->gt, (size_t)c->Bmax * c->N));
+        int rc = copy_in(c, c->gt, gt, (size_t)c->B * c->N, 0);
+        if (rc) return rc;
+        d_gt = c->gt;
+    }
+    HIPCHK(launch_metrics(c->stream, x, d_gt, c->acc, c->B, (int)c->N));
+    std::vector<double> h((size_t)c->B * 2);
+    int rc = copy_out(c, h.data(), c->acc, h.size() * sizeof(double), 0);
+    if (rc) return rc;
+    for (int b = 0; b < c->B; ++b) {
+        const double mse = h[2 * b] / (double)c->N;
+        psnr[b] = (mse == 0.0) ? INFINITY : 20.0 * log10(255.0 / sqrt(mse));
+        re[b] = sqrt(h[2 * b]) / sqrt(h[2 * b + 1]);
+    }
+    return PNP_OK;
+}
+
+int pnp_timer_start(pnp_ctx* c) { CTX(c); HIPCHK(hipEventRecord(c->ev0, c->stream)); return PNP_OK; }
+int pnp_timer_stop(pnp_ctx* c, float* ms) {
+    CTX(c);
+    if (!ms) return fail(PNP_E_ARG, "pnp_timer_stop: null");
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PNP_OK;
+}
+
+int pnp_kernels_per_iteration(pnp_ctx* c) {
+    if (!c) return 0;
+    return use_fused(c) ? fused256_kernels_per_iteration() : 3;
+}
+const char* pnp_path_name(pnp_ctx* c) { return (c && use_fused(c)) ? "fused" : "generic"; }
+
+}  // extern "C"

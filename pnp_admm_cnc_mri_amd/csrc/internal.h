@@ -1,0 +1,73 @@
+// Internal declarations shared by the translation units of libpnpmri.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnp {
+
+// Scalars of the z/w update, pre-combined on the host in double and rounded once to float.
+struct ProxParams {
+    float thr;      // L1: reo*lambda1            CNC: alpha*reo*lambda1   (outer soft threshold)
+    float c1;       // CNC: 1-alpha
+    float c2;       // CNC: alpha
+    float c3;       // CNC: alpha*reo*lambda1*b
+    float ib;       // CNC: 1/b   (inner clip level: z - soft(z,1/b) == clip(z,-1/b,1/b))
+};
+
+enum RowIn  { IN_COMPLEX = 0, IN_REAL = 1, IN_REAL_DIFF = 2 };
+enum RowEpi { EPI_COMPLEX = 0, EPI_ABS_REAL = 1, EPI_ABS_COMPLEX = 2, EPI_L1 = 3, EPI_CNC = 4 };
+enum ColMid { MID_NONE = 0, MID_BLEND = 1, MID_MASK = 2, MID_RESID = 3, MID_MASK_ADD = 4 };
+
+struct RowArgs {
+    const float2* cin;     // IN_COMPLEX
+    const float*  rin0;    // IN_REAL / IN_REAL_DIFF (minuend)
+    const float*  rin1;    // IN_REAL_DIFF (subtrahend)
+    float2*       cout;    // EPI_COMPLEX
+    float*        x_out;   // EPI_ABS_* (required) / EPI_L1, EPI_CNC (optional, may be null)
+    float*        z;       // EPI_L1 / EPI_CNC: read old, write new
+    float*        w;
+    float         scale;   // applied to the transform output
+    ProxParams    prox;
+    int           nrows;   // B*H
+};
+
+struct ColArgs {
+    const float2*  in;
+    float2*        out;        // may alias in
+    const float2*  y;          // MID_BLEND / MID_RESID: measurements; MID_MASK_ADD: noise
+    const uint8_t* mask_bank;  // [K][H][W]
+    const int32_t* mask_id;    // [B] or null
+    float          c;          // MID_BLEND: 1/(1+La2)
+    int            y_per_slice;// MID_MASK_ADD: 0 = one [H][W] noise array for all slices
+    int            B;
+};
+
+// generic path (kernels_generic.hip); H, W in {256, 512}
+hipError_t launch_rows(hipStream_t s, int W, RowIn in, bool inv, RowEpi epi, const RowArgs& a);
+hipError_t launch_cols(hipStream_t s, int H, int W, bool pre_fwd, ColMid mid, bool post_inv, const ColArgs& a);
+hipError_t upload_twiddles();       // fills the __device__ tables of the current device
+
+// pointwise
+hipError_t launch_prox(hipStream_t s, bool cnc, const float* x, float* z, float* w, ProxParams p, size_t n);
+hipError_t launch_combine(hipStream_t s, const float* z, const float* x, const float* w, const float* sden,
+                          float* t, float c1, float c2, float c3, size_t n);
+hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* o, size_t n);
+hipError_t launch_dual_clamp(hipStream_t s, float* x, float* z, float* w, size_t n);
+hipError_t launch_metrics(hipStream_t s, const float* x, const uint8_t* gt, double* acc /*[B][2]*/, int B, int N);
+
+// fused 256x256 path (kernels_fused256.hip): state resident in the ctx, two slices packed into
+// one complex transform.  See DESIGN.md.
+struct Fused256;
+Fused256*  fused256_create(int Bmax, hipError_t* err);
+void       fused256_destroy(Fused256*);
+// builds the Hermitian-symmetrised measurement / mask tables from y and the masks
+hipError_t fused256_prepare(Fused256*, hipStream_t s, const float2* y, const uint8_t* mask_bank,
+                            const int32_t* mask_id, int B);
+// iters iterations of x=dc(z,w); (z,w)=prox(x,z,w) on z,w [B][256][256]; x written on the last
+hipError_t fused256_run(Fused256*, hipStream_t s, float* z, float* w, float* x, int B, int iters,
+                        bool cnc, float dc_c, ProxParams p);
+// one data-consistency step on caller pointers
+hipError_t fused256_dc(Fused256*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
+int        fused256_kernels_per_iteration();
+
+}  // namespace pnp

@@ -1,0 +1,345 @@
+"""GPU parity tests: the HIP path (through the C ABI, ctypes) against the oracle and the golden
+vectors from the unmodified reference.  Run on the MI355X box with `pytest -m gpu`.
+
+Tolerances (fp32 device arithmetic vs the float64 oracle):
+  * single transforms / operators : relative L2 <= 2e-6   (fp32 FFT round-off, 256..512 points)
+  * whole solves, north-star bar   : relative L2 <= 1e-5 and |dPSNR| <= 0.01 dB
+    -- holds for ADMM_L1 at any iteration count and for ADMM_CNC up to ~40 iterations; the
+    committed CNC defaults (reo*lambda*b = 1.6 > 1) make the iteration map locally expansive, so
+    fp32 round-off grows ~1.08x per iteration in *any* fp32 implementation (NumPy's own
+    float32 run: 1e-5 at 50 iterations, 4e-4 at 100).  Those cases are pinned
+    per iteration (teacher-forced, <= 2e-6), by PSNR within 0.01 dB, and end to end against the
+    NumPy-float32 precision control (test_cnc_100_iterations_config2).
+"""
+import numpy as np
+import pytest
+
+from oracle import admm_oracle as O
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+MASKS = {'random30': 'Q_Random30', 'radial30': 'Q_Radial30', 'cartesian30': 'Q_Cartesian30'}
+
+
+@pytest.fixture(scope='module')
+def P():
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import _lib
+    assert _lib.device_count() >= 1, 'no HIP device visible: GPU tests must not pass silently'
+    return P
+
+
+@pytest.fixture(scope='module')
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _masks(golden_inputs):
+    return np.stack([golden_inputs['masks'][MASKS[k]] for k in ('random30', 'radial30', 'cartesian30')]).astype(np.uint8)
+
+
+def _synthetic(B, masks, H=256, W=256, mask_id=None):
+    mask_id = np.arange(B) % len(masks) if mask_id is None else mask_id
+    imgs, ys = [], []
+    for b in range(B):
+        img, y = O.synthetic_problem(b, masks[mask_id[b]], H, W)
+        imgs.append(img)
+        ys.append(y)
+    return np.stack(imgs), np.stack(ys), mask_id.astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# transforms and operators
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('H,W', [(256, 256), (512, 512), (256, 512), (512, 256)])
+def test_fft2_roundtrip_and_numpy(P, torch, H, W):
+    rng = np.random.default_rng(1)
+    B = 3
+    a = (rng.standard_normal((B, H, W)) + 1j * rng.standard_normal((B, H, W))).astype(np.complex64)
+    with P.Engine(H, W, Bmax=B) as eng:
+        t = torch.from_numpy(a).cuda()
+        k = P.utils_pnp.fft2(eng, t)
+        assert rel_l2(k.cpu().numpy(), np.fft.fft2(a.astype(np.complex128))) <= 2e-6
+        back = P.utils_pnp.ifft2(eng, k)
+        assert rel_l2(back.cpu().numpy(), a) <= 2e-6
+        ki = P.utils_pnp.ifft2(eng, t)
+        assert rel_l2(ki.cpu().numpy(), np.fft.ifft2(a.astype(np.complex128))) <= 2e-6
+
+
+def test_fft2_linearity_and_parseval(P, torch):
+    rng = np.random.default_rng(2)
+    a = (rng.standard_normal((2, 256, 256)) + 1j * rng.standard_normal((2, 256, 256))).astype(np.complex64)
+    with P.Engine(256, 256, Bmax=2) as eng:
+        ta = torch.from_numpy(a).cuda()
+        k = P.utils_pnp.fft2(eng, ta)
+        e_x = float((ta.abs() ** 2).sum())
+        e_k = float((k.abs() ** 2).sum()) / 65536
+        assert abs(e_x - e_k) <= 1e-5 * e_x
+        k2 = P.utils_pnp.fft2(eng, 2.5 * ta)
+        assert rel_l2(k2.cpu().numpy(), 2.5 * k.cpu().numpy()) <= 1e-6
+        delta = torch.zeros((1, 256, 256), dtype=torch.complex64, device='cuda')
+        delta[0, 0, 0] = 1
+        assert torch.allclose(P.utils_pnp.fft2(eng, delta), torch.ones_like(delta))
+
+
+def test_operators_A_AH_Df(P, torch, golden_inputs):
+    masks = _masks(golden_inputs)
+    B = 3
+    imgs, ys, mid = _synthetic(B, masks)
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.upload(ys, masks, mid)
+        x = torch.from_numpy(imgs).cuda()
+        k = P.utils_pnp.A(eng, x).cpu().numpy()
+        for b in range(B):
+            assert rel_l2(k[b], O.A(imgs[b].astype(np.float64), masks[mid[b]])) <= 2e-6
+        kk = torch.from_numpy(ys.astype(np.complex64)).cuda()
+        ah = P.utils_pnp.AH(eng, kk).cpu().numpy()
+        for b in range(B):
+            assert rel_l2(ah[b], O.AH(ys[b], masks[mid[b]])) <= 2e-6
+        df = P.utils_pnp.Df(eng, x).cpu().numpy()
+        for b in range(B):
+            # the device holds y as complex64: compare against the oracle on the same y
+            ref = O.Df(imgs[b].astype(np.float64), masks[mid[b]].astype(np.float64), ys[b].astype(np.complex64).astype(np.complex128))
+            assert rel_l2(df[b], ref) <= 5e-6
+        # adjointness <A x, k> == N <x, A^H k>  (ifft2 carries 1/N)
+        lhs = np.vdot(k[0], ys[0])
+        rhs = 65536 * np.vdot(imgs[0].astype(np.complex128), ah[0])
+        assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+def test_synthesize_and_init(P, golden_inputs):
+    """y = fft2(img)*mask + noises and z0 = |ifft2(y)| on the reference's real inputs (S4:101-109)."""
+    img = O.requantise(golden_inputs['gray'])
+    mask = golden_inputs['masks']['Q_Random30']
+    y_ref = O.synthesize(img, mask.astype(np.float64), golden_inputs['noises'])
+    with P.Engine(256, 256, Bmax=1) as eng:
+        eng.synthesize(img, golden_inputs['noises'], mask)
+        y = eng.download_y()[0]
+        assert rel_l2(y, y_ref) <= 2e-6
+        eng.init_state()
+        z, w = eng.get_state()
+        x0, _, _ = O.init_state(y_ref)
+        assert rel_l2(z[0], x0) <= 2e-6
+        assert not w.any()
+
+
+@pytest.mark.parametrize('H,W', [(256, 256), (512, 512)])
+def test_dc_step_teacher_forced(P, torch, golden_inputs, H, W):
+    """One x-update from identical (z, w): the per-iteration parity that bounds everything else."""
+    if H == 256:
+        masks = _masks(golden_inputs)
+    else:
+        masks = np.stack([O.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+    B = 4
+    imgs, ys, mid = _synthetic(B, masks, H, W)
+    rng = np.random.default_rng(5)
+    z = rng.uniform(0, 1, (B, H, W)).astype(np.float32)
+    w = rng.uniform(-0.1, 0.1, (B, H, W)).astype(np.float32)
+    for fast in (0, 1):
+        with P.Engine(H, W, Bmax=B) as eng:
+            eng.set_fast_path(fast)
+            eng.upload(ys, masks, mid)
+            x = P.utils_pnp.dc_solve(eng, torch.from_numpy(z).cuda(), torch.from_numpy(w).cuda(), 0.05).cpu().numpy()
+            for b in range(B):
+                ref = O.dc_step(z[b].astype(np.float64), w[b].astype(np.float64),
+                                ys[b].astype(np.complex64).astype(np.complex128), masks[mid[b]], 0.05)
+                assert rel_l2(x[b], ref) <= 2e-6, (fast, b)
+
+
+def test_prox_kernels(P, torch):
+    rng = np.random.default_rng(7)
+    B = 2
+    x = rng.uniform(0, 1, (B, 256, 256)).astype(np.float32)
+    z = rng.uniform(-0.05, 1, (B, 256, 256)).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (B, 256, 256)).astype(np.float32)
+    masks = np.ones((1, 256, 256), np.uint8)
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.upload(np.zeros((B, 256, 256), np.complex64), masks)
+        tx, tz, tw = (torch.from_numpy(a.copy()).cuda() for a in (x, z, w))
+        P.utils_pnp.prox_l1(eng, tx, tz, tw, 0.0015)
+        zr, wr = O.l1_step(x.astype(np.float64), z.astype(np.float64), w.astype(np.float64), 0.1, 0.015)
+        assert np.abs(tz.cpu().numpy() - zr).max() <= 2e-7 and np.abs(tw.cpu().numpy() - wr).max() <= 2e-7
+        tx, tz, tw = (torch.from_numpy(a.copy()).cuda() for a in (x, z, w))
+        P.utils_pnp.prox_cnc(eng, tx, tz, tw, 0.45, 0.5, 0.05, 64)
+        zr, wr = O.cnc_step(x.astype(np.float64), z.astype(np.float64), w.astype(np.float64), 0.45, 0.5, 0.05, 64)
+        assert np.abs(tz.cpu().numpy() - zr).max() <= 5e-7 and np.abs(tw.cpu().numpy() - wr).max() <= 5e-7
+
+
+# ------------------------------------------------------------------------------------------------
+# whole solves against the golden vectors of the unmodified reference (config 1)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fast', [0, 1])
+@pytest.mark.parametrize('n', [1, 2, 5, 10, 50])
+def test_admm_l1_golden(P, golden_inputs, golden_admm, n, fast):
+    img = O.requantise(golden_inputs['gray'])
+    mask = golden_inputs['masks']['Q_Random30']
+    with P.Engine(256, 256, Bmax=1) as eng:
+        eng.set_fast_path(fast)
+        eng.synthesize(img, golden_inputs['noises'], mask)
+        eng.init_state()
+        eng.admm_l1(n, 0.1, 0.015)                     # S1:171 presets
+        x = eng.x()[0]
+    ref = golden_admm['l1_random30_it%d' % n]
+    assert rel_l2(x, ref) <= 1e-5
+    gt = golden_inputs['gray']
+    assert abs(O.calculate_psnr(x.astype(np.float64) * 255, gt) - O.calculate_psnr(ref.astype(np.float64) * 255, gt)) <= 0.01
+
+
+@pytest.mark.parametrize('fast', [0, 1])
+@pytest.mark.parametrize('n', [1, 2, 5, 10, 50])
+def test_admm_cnc_golden(P, golden_inputs, golden_admm, n, fast):
+    img = O.requantise(golden_inputs['gray'])
+    mask = golden_inputs['masks']['Q_Random30']
+    with P.Engine(256, 256, Bmax=1) as eng:
+        eng.set_fast_path(fast)
+        eng.synthesize(img, golden_inputs['noises'], mask)
+        eng.init_state()
+        eng.admm_cnc(n, 0.45, 0.5, 0.05, 64)           # S4:176 presets (expansive: reo*lambda*b = 1.6)
+        x = eng.x()[0]
+    ref = golden_admm['cnc_random30_it%d' % n]
+    tol = 1e-5 if n <= 10 else 1e-4                    # see module docstring
+    assert rel_l2(x, ref) <= tol
+    gt = golden_inputs['gray']
+    assert abs(O.calculate_psnr(x.astype(np.float64) * 255, gt) - O.calculate_psnr(ref.astype(np.float64) * 255, gt)) <= 0.01
+
+
+def test_solver_entry_points_on_reference_inputs(P, golden_inputs, golden_admm, known_answers, tmp_path):
+    """ADMM_L1 / ADMM_CNC called the way the reference's __main__ calls them (S1:194, S4:202),
+    images handed in instead of read from testsets/Set1; metrics must reproduce the log lines."""
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    gray = golden_inputs['gray'][None]
+    out, info = P.ADMM_L1(mask, golden_inputs['noises'], images=gray, results=str(tmp_path), return_info=True,
+                          **P.PRESETS['ADMM_L1'])
+    assert len(out) == 22 and out[0].dtype == np.float64 and out[1].dtype == np.uint8
+    assert rel_l2(out[0], golden_admm['l1_random30_it50']) <= 1e-5
+    assert abs(info['psnr'][0] - 23.8683) <= 0.01 and abs(info['re'][0] - 0.2028) <= 1e-4
+    out, info = P.ADMM_CNC(mask, golden_inputs['noises'], images=gray, results=str(tmp_path), return_info=True,
+                           **P.PRESETS['ADMM_CNC'])
+    assert rel_l2(out[0], golden_admm['cnc_random30_it50']) <= 1e-4
+    assert abs(info['psnr'][0] - 24.5765) <= 0.01 and abs(info['re'][0] - 0.1870) <= 1e-4
+
+
+@pytest.mark.parametrize('mname', ['radial30', 'cartesian30'])
+def test_other_masks_golden(P, golden_inputs, golden_admm, mname):
+    img = O.requantise(golden_inputs['gray'])
+    mask = golden_inputs['masks'][MASKS[mname]]
+    with P.Engine(256, 256, Bmax=1) as eng:
+        eng.synthesize(img, golden_inputs['noises'], mask)
+        eng.init_state()
+        eng.admm_l1(50, 0.1, 0.015)
+        assert rel_l2(eng.x()[0], golden_admm['l1_%s_it50' % mname]) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# batched synthetic workload (config 2 shape, small B) vs the oracle, mixed masks, odd B
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fast', [0, 1])
+@pytest.mark.parametrize('B', [1, 5, 8])
+def test_batched_mixed_masks_vs_oracle(P, golden_inputs, B, fast):
+    masks = _masks(golden_inputs)
+    imgs, ys, mid = _synthetic(B, masks)
+    with P.Engine(256, 256, Bmax=8) as eng:
+        eng.set_fast_path(fast)
+        eng.upload(ys, masks, mid)
+        eng.init_state()
+        eng.admm_l1(100, 0.1, 0.015)
+        xl1 = eng.x()
+        eng.init_state()
+        eng.admm_cnc(30, 0.45, 0.5, 0.05, 64)
+        xcnc = eng.x()
+    for b in range(B):
+        y64 = ys[b].astype(np.complex64).astype(np.complex128)
+        assert rel_l2(xl1[b], O.admm_l1(y64, masks[mid[b]], 100, 0.1, 0.015)) <= 1e-5, b
+        assert rel_l2(xcnc[b], O.admm_cnc(y64, masks[mid[b]], 30, 0.45, 0.5, 0.05, 64)) <= 1e-5, b
+
+
+@pytest.mark.parametrize('fast', [0, 1])
+def test_cnc_100_iterations_config2(P, golden_inputs, fast):
+    """Config 2's iteration count (100) with the committed CNC presets.  The map is locally
+    expansive, so fp32 round-off grows ~1.08x per iteration in any fp32 arithmetic: NumPy's own
+    complex64/float32 run of the same lines ends 4e-4 away from the float64 reference.  Pinned:
+      (a) teacher-forced: from the oracle's (z, w) at iterations 24, 49, 74, 98 one device
+          iteration reproduces the oracle's next (x, z, w) to <= 2e-6 -- every step is right;
+      (b) end to end: deviation from float64 <= 3x the deviation of the NumPy-float32 control,
+          and PSNR against the ground truth within 0.01 dB of the reference's."""
+    masks = _masks(golden_inputs)[:1]
+    B = 2
+    imgs, ys, mid = _synthetic(B, masks, mask_id=np.zeros(B, int))
+    y64 = [ys[b].astype(np.complex64).astype(np.complex128) for b in range(B)]
+    marks = (24, 49, 74, 98, 99)
+    traces = [O.admm_cnc(y64[b], masks[0], 100, trace=marks + (25, 50, 75, 100))[1] for b in range(B)]
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.set_fast_path(fast)
+        eng.upload(ys, masks, mid)
+        for it in (24, 49, 74, 98):                                        # (a)
+            z = np.stack([traces[b][it][1] for b in range(B)]).astype(np.float32)
+            w = np.stack([traces[b][it][2] for b in range(B)]).astype(np.float32)
+            eng.set_state(z, w)
+            eng.admm_cnc(1, 0.45, 0.5, 0.05, 64)
+            x1 = eng.x()
+            z1, w1 = eng.get_state()
+            for b in range(B):
+                xr, zr, wr = O.dc_step(z[b].astype(np.float64), w[b].astype(np.float64), y64[b], masks[0], 0.05), None, None
+                zr, wr = O.cnc_step(xr, z[b].astype(np.float64), w[b].astype(np.float64), 0.45, 0.5, 0.05, 64)
+                assert rel_l2(x1[b], xr) <= 2e-6 and rel_l2(z1[b], zr) <= 2e-6
+                assert np.abs(w1[b] - wr).max() <= 2e-6
+        eng.init_state()                                                   # (b)
+        eng.admm_cnc(100, 0.45, 0.5, 0.05, 64)
+        x = eng.x()
+    for b in range(B):
+        ref = traces[b][100][0]
+        control = rel_l2(O.admm_cnc_f32(y64[b], masks[0], 100), ref)
+        assert rel_l2(x[b], ref) <= 3 * control, (rel_l2(x[b], ref), control)
+        gt = np.uint8(np.round(imgs[b] * 255))
+        assert abs(O.calculate_psnr(x[b].astype(np.float64) * 255, gt) - O.calculate_psnr(ref * 255, gt)) <= 0.01
+
+
+def test_512_mixed_masks_vs_oracle(P):
+    """config 5 shape (512x512, mask bank of 3, mask_id = b % 3), small batch."""
+    H = W = 512
+    masks = np.stack([O.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+    assert all(0.25 < m.mean() < 0.35 for m in masks)
+    B = 3
+    imgs, ys, mid = _synthetic(B, masks, H, W)
+    with P.Engine(H, W, Bmax=B) as eng:
+        eng.upload(ys, masks, mid)
+        eng.init_state()
+        eng.admm_cnc(20, 0.45, 0.5, 0.05, 64)
+        x = eng.x()
+    for b in range(B):
+        y64 = ys[b].astype(np.complex64).astype(np.complex128)
+        assert rel_l2(x[b], O.admm_cnc(y64, masks[mid[b]], 20, 0.45, 0.5, 0.05, 64)) <= 1e-5
+
+
+def test_run_is_resumable_and_deterministic(P, golden_inputs):
+    """10 + 15 iterations == 25 iterations bit for bit; two runs agree bit for bit."""
+    masks = _masks(golden_inputs)
+    imgs, ys, mid = _synthetic(4, masks)
+    outs = []
+    with P.Engine(256, 256, Bmax=4) as eng:
+        eng.upload(ys, masks, mid)
+        for split in ((25,), (10, 15), (25,)):
+            eng.init_state()
+            for n in split:
+                eng.admm_cnc(n, 0.45, 0.5, 0.05, 64)
+            outs.append(eng.x().copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_error_behaviour(P):
+    from pnp_admm_cnc_mri_amd._lib import PnpError
+    with pytest.raises(PnpError):
+        P.Engine(100, 256)
+    with P.Engine(256, 256, Bmax=2) as eng:
+        with pytest.raises(PnpError):
+            eng.init_state()                            # nothing uploaded
+        with pytest.raises(PnpError):
+            eng.upload(np.zeros((3, 256, 256), np.complex64), np.ones((256, 256), np.uint8))   # B > Bmax
+        eng.upload(np.zeros((2, 256, 256), np.complex64), np.ones((256, 256), np.uint8))
+        with pytest.raises(PnpError):
+            eng.x()                                     # no iteration yet
+        with pytest.raises(PnpError):
+            eng.admm_l1(1, 0.1, 0.0)                    # reo must be > 0
