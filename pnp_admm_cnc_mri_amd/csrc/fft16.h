@@ -1,0 +1,133 @@
+// In-register 16-point DFT and the two halves of the 16-lane cooperative 256-point FFT used by
+// the fused kernels.  __host__ __device__ so the index math is unit-tested under g++ on the CPU
+// (tests/test_host_cores.py) exactly as it runs on gfx950.
+//
+// 256 = 16 x 16 Cooley-Tukey over 16 cooperating lanes (t = 0..15), 16 points per lane:
+//   in : lane t holds x[t + 16 j],  j = 0..15
+//   (1) dft16 over j            -> Y[t][k2]
+//   (2) twiddle by W256^(t*k2)   (tw[k2], generated in fp64, conj for the inverse direction)
+//   (3) 16x16 transpose between the lanes (through LDS): lane k2 receives Y[n1][k2], n1 = 0..15
+//   (4) dft16 over n1           -> lane k2 holds X[k2 + 16 k1], k1 = 0..15
+// so input and output have the same "stride-16" distribution, and a forward transform can feed
+// a pointwise stage and an inverse transform with no re-ordering in between.
+#pragma once
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PNP_HD __host__ __device__ __forceinline__
+#else
+#define PNP_HD inline
+#endif
+
+namespace pnp {
+
+struct c32 {
+    float x, y;
+};
+
+PNP_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+PNP_HD c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
+PNP_HD c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+PNP_HD c32 mul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+PNP_HD c32 mulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a*conj(b)
+template <bool INV> PNP_HD c32 tmul(c32 a, c32 w) { return INV ? mulc(a, w) : mul(a, w); }
+// multiply by -i (forward) / +i (inverse)
+template <bool INV> PNP_HD c32 rot(c32 a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+
+template <bool INV>
+PNP_HD void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
+    const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+
+// a[k] <- sum_n a[n] W16^(nk)   (W16 = exp(-2 pi i/16); conjugated when INV), natural order.
+template <bool INV>
+PNP_HD void dft16(c32 (&a)[16]) {
+    constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
+    constexpr float H = 0.70710678118654752f;    // sqrt(1/2)
+    // step 1: for n0: DFT4 over n1 of a[n0 + 4 n1]  -> b[n0][k1] stored at a[n0 + 4 k1]
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) dft4<INV>(a[n0], a[n0 + 4], a[n0 + 8], a[n0 + 12]);
+    // step 2: b[n0][k1] *= W16^(n0*k1)   (forward values; tmul conjugates for INV)
+    a[1 + 4] = tmul<INV>(a[1 + 4], mk(C1, -S1));     // W^1
+    a[1 + 8] = tmul<INV>(a[1 + 8], mk(H, -H));       // W^2
+    a[1 + 12] = tmul<INV>(a[1 + 12], mk(S1, -C1));   // W^3
+    a[2 + 4] = tmul<INV>(a[2 + 4], mk(H, -H));       // W^2
+    a[2 + 8] = rot<INV>(a[2 + 8]);                   // W^4 = -i
+    a[2 + 12] = tmul<INV>(a[2 + 12], mk(-H, -H));    // W^6
+    a[3 + 4] = tmul<INV>(a[3 + 4], mk(S1, -C1));     // W^3
+    a[3 + 8] = tmul<INV>(a[3 + 8], mk(-H, -H));      // W^6
+    a[3 + 12] = tmul<INV>(a[3 + 12], mk(-C1, S1));   // W^9
+    // step 3: for k1: DFT4 over n0 of b[n0][k1] -> X[k1 + 4 k0]; b[n0][k1] sits at a[n0 + 4 k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+    // now a[4 k1 + k0] = X[k1 + 4 k0]: transpose the 4x4 index to natural order
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const c32 tmp = a[4 * i + j];
+            a[4 * i + j] = a[4 * j + i];
+            a[4 * j + i] = tmp;
+        }
+}
+
+// steps (1)+(2) for one lane; tw[k] = W256^(t*k) (forward values)
+template <bool INV>
+PNP_HD void fft256_head(c32 (&a)[16], const c32 (&tw)[16]) {
+    dft16<INV>(a);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[k]);
+}
+// step (4)
+template <bool INV>
+PNP_HD void fft256_tail(c32 (&a)[16]) { dft16<INV>(a); }
+
+// ----------------------------------------------------------------------------------------------
+// z / w updates shared by all kernels (S1:123-126, S4:127-132)
+// ----------------------------------------------------------------------------------------------
+struct ProxCoef {
+    float thr, c1, c2, c3, ib;
+};
+
+PNP_HD float soft_thr(float a, float c) {
+    const float m = (a < 0 ? -a : a) - c;
+    const float r = m > 0 ? m : 0.0f;
+    return a < 0 ? -r : r;
+}
+PNP_HD void prox_l1_pt(float x, float& z, float& w, const ProxCoef& p) {
+    const float u = x + w;
+    z = soft_thr(u, p.thr);
+    w = u - z;
+}
+PNP_HD void prox_cnc_pt(float x, float& z, float& w, const ProxCoef& p) {
+    const float u = x + w;
+    const float cz = z < -p.ib ? -p.ib : (z > p.ib ? p.ib : z);   // z - soft(z, 1/b)
+    const float t = p.c1 * z + p.c2 * u + p.c3 * cz;
+    z = soft_thr(t, p.thr);
+    w = u - z;
+}
+
+// ----------------------------------------------------------------------------------------------
+// two-slice k-space blend of the fused column kernel.
+//   P = C[k],  Q = C[-k]  with  C = F(va + i vb)  (va, vb real slices)
+//   Va = (P + conj Q)/2, Vb = (P - conj Q)/(2i)
+//   Xs = Vs (1 - c Mh_s) + c Yh_s      (Hermitian-symmetrised data-consistency blend)
+//   P' = Xa + i Xb,  Q' = conj(Xa) + i conj(Xb)
+// ma, mb in {0,1,2} = 2*Mh;  ch = c/2.
+// ----------------------------------------------------------------------------------------------
+PNP_HD void blend_pair(c32& P, c32& Q, c32 yha, c32 yhb, int ma, int mb, float c, float ch) {
+    const float sx = P.x + Q.x, sy = P.y - Q.y;     // P + conj Q
+    const float dx = P.x - Q.x, dy = P.y + Q.y;     // P - conj Q
+    const float Aa = 0.5f - 0.5f * ch * (float)ma;  // (1 - c*Mh_a)/2
+    const float Ab = 0.5f - 0.5f * ch * (float)mb;
+    const float xax = Aa * sx + c * yha.x, xay = Aa * sy + c * yha.y;
+    const float xbx = Ab * dy + c * yhb.x, xby = -Ab * dx + c * yhb.y;
+    P = mk(xax - xby, xay + xbx);
+    Q = mk(xax + xby, xbx - xay);
+}
+
+}  // namespace pnp

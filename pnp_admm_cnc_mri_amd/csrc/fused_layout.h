@@ -1,0 +1,39 @@
+// Data layout of the fused 256x256 path (shared by kernels_fused256.hip and the g++ host test).
+//
+// Two real slices a = 2p, b = 2p+1 travel as ONE complex field c = v_a + i v_b ("pair" p), so a
+// single complex 2-D FFT transforms both.  k-space blend happens on the Hermitian-symmetrised
+// measurements:
+//     Yh_s[k] = (m_s[k] y_s[k] + m_s[-k] conj(y_s[-k])) / 2,     Mh_s[k] = (m_s[k] + m_s[-k]) / 2
+// needed only on the half plane k2 = 0..128 because the column kernel processes column k2 and its
+// mirror 256-k2 together.
+//
+//   T  : [pair][r][k2]           c32     row-FFT'd field, 512 KiB per pair (in place both ways)
+//   Yh : [pair][k2:129][j:16][t:16] float4 {Yh_a.re, Yh_a.im, Yh_b.re, Yh_b.im} at k1 = t + 16 j
+//   Mh : [pair][k2:129][t:16]    u64     nibble j = (2 Mh_a) | (2 Mh_b) << 2 at k1 = t + 16 j
+// (j, t) is exactly the (register, lane) a value has after the cooperative FFT of fft16.h, so a
+// lane's 16 blend operands are 16 coalesced 16-byte loads and one 8-byte load.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "fft16.h"
+
+namespace pnp {
+
+constexpr int F_N = 256;
+constexpr int F_HALF = 129;                  // k2 = 0..128
+
+PNP_HD size_t yh_index(int pair, int k2, int j, int t) { return (((size_t)pair * F_HALF + k2) * 16 + j) * 16 + t; }
+PNP_HD size_t mh_index(int pair, int k2, int t) { return ((size_t)pair * F_HALF + k2) * 16 + t; }
+
+// Hermitian-symmetrised measurement and mask code of one slice at (k1, k2).
+// y, mask: the slice's [256][256] arrays.
+PNP_HD void hermitian_entry(const c32* y, const uint8_t* mask, int k1, int k2, c32& yh, int& code) {
+    const int i1 = k1 * F_N + k2;
+    const int i2 = ((F_N - k1) & 255) * F_N + ((F_N - k2) & 255);
+    const int m1 = mask[i1] != 0, m2 = mask[i2] != 0;
+    const c32 y1 = y[i1], y2 = y[i2];
+    yh = mk(0.5f * ((float)m1 * y1.x + (float)m2 * y2.x), 0.5f * ((float)m1 * y1.y - (float)m2 * y2.y));
+    code = m1 + m2;
+}
+
+}  // namespace pnp

@@ -1,10 +1,367 @@
-// placeholder until the fused path lands: the ABI falls back to the generic kernels.
+// Fused gfx950 kernels for 256x256 slices: one ADMM iteration = 2 launches.
+//
+//   k_frows : per 16 rows of a slice PAIR (a = 2p, b = 2p+1, carried as c = v_a + i v_b):
+//             [inverse row FFT of T -> x = |Re|,|Im| / 65536 -> L1/CNC z-update -> dual update]
+//             -> v = z - w -> forward row FFT -> T          (reference lines S4:119-132)
+//   k_fcols : per 16 column pairs (k2, 256-k2) of a slice pair:
+//             forward column FFT of column k2, inverse-direction FFT of column 256-k2 (so that
+//             lane/register (t, j) holds C[k] and C[-k] together -- no exchange for the
+//             two-slice unpack), Hermitian data-consistency blend against Yh/Mh, and the
+//             inverse column transforms, in place in T.   (S4:120-123)
+//
+// HBM bytes per slice-iteration: z,w read+write 16 N + T write/read twice 16 N (8 N per slice
+// as two slices share a complex field) + Yh 4 N + Mh ~0 = 36 N, against 57 N for the plain c2c
+// three-kernel formulation.  Layouts: fused_layout.h; cores: fft16.h.
+//
+// FFT-256 = 16 lanes x 16 points (radix-16 in registers, one 16x16 transpose through LDS).
+//   rows   : lanes of a 16-group are consecutive (one row each), global access is 16 B/lane
+//            through an LDS staging tile;
+//   columns: a group's lanes sit 16 apart (lane = k2_local + 16*t_quad, 4 waves) so every
+//            global access instruction covers 128-B row segments of 16 neighbouring columns.
 #include "internal.h"
+#include "fused_layout.h"
+#include <math.h>
+
 namespace pnp {
-Fused256* fused256_create(int, hipError_t* err) { *err = hipErrorNotSupported; return nullptr; }
-void fused256_destroy(Fused256*) {}
-hipError_t fused256_prepare(Fused256*, hipStream_t, const float2*, const uint8_t*, const int32_t*, int) { return hipErrorNotSupported; }
-hipError_t fused256_run(Fused256*, hipStream_t, float*, float*, float*, int, int, bool, float, ProxParams) { return hipErrorNotSupported; }
-hipError_t fused256_dc(Fused256*, hipStream_t, const float*, const float*, float*, int, float) { return hipErrorNotSupported; }
-int fused256_kernels_per_iteration() { return 2; }
+
+__device__ c32 g_twf[256];
+
+struct Fused256 {
+    int Bmax = 0, np = 0;
+    c32* T = nullptr;
+    float4* Yh = nullptr;
+    unsigned long long* Mh = nullptr;
+};
+
+static inline ProxCoef to_coef(const ProxParams& p) {
+    ProxCoef c;
+    c.thr = p.thr; c.c1 = p.c1; c.c2 = p.c2; c.c3 = p.c3; c.ib = p.ib;
+    return c;
 }
+
+// ------------------------------------------------------------------------------------------
+// table preparation (once per uploaded problem)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fprepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
+                                                  float4* Yh, unsigned long long* Mh, int B) {
+    __shared__ int nib[256];
+    const int tid = threadIdx.x, j = tid >> 4, t = tid & 15;
+    const int k2 = blockIdx.x, pair = blockIdx.y, k1 = t + 16 * j;
+    c32 yh[2] = {mk(0.f, 0.f), mk(0.f, 0.f)};
+    int code[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int sl = 2 * pair + s;
+        if (sl < B) {
+            const int mid = mask_id ? mask_id[sl] : 0;
+            hermitian_entry(y + (size_t)sl * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh[s], code[s]);
+        }
+    }
+    Yh[yh_index(pair, k2, j, t)] = make_float4(yh[0].x, yh[0].y, yh[1].x, yh[1].y);
+    nib[tid] = code[0] | (code[1] << 2);
+    __syncthreads();
+    if (tid < 16) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v |= (unsigned long long)nib[jj * 16 + tid] << (4 * jj);
+        Mh[mh_index(pair, k2, tid)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rows
+// ------------------------------------------------------------------------------------------
+struct FRowArgs {
+    c32* T;
+    const float* z_in;
+    const float* w_in;
+    float* z_out;
+    float* w_out;
+    float* x_out;
+    int B;
+    float scale;
+    ProxCoef prox;
+};
+
+constexpr int RP = 272;    // staging pitch (c32) of a row in LDS: 272 % 32 == 16 -> two rows per
+                           // 32-lane ds_read_b64 group land on disjoint bank halves
+constexpr int XP = 289;    // exchange region per 16-lane group, runs of 17 (289 % 32 == 1)
+
+// 16x16 transpose between the lanes of a group; region = this group's XP-sized LDS area
+template <bool INV>
+__device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32 (&tw)[16], c32* region, int t) {
+    fft256_head<INV>(a, tw);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) region[k * 17 + t] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) a[n] = region[t * 17 + n];
+    __syncthreads();
+    fft256_tail<INV>(a);
+}
+
+// PROX: 0 none, 1 L1, 2 CNC
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
+    __shared__ __attribute__((aligned(16))) c32 lds[16 * XP];
+    const int tid = threadIdx.x, g = tid >> 4, t = tid & 15;
+    const int pair = blockIdx.x >> 4, r0 = (blockIdx.x & 15) * 16;
+    const int sa = 2 * pair, sb = sa + 1;
+    const bool has_b = sb < p.B;
+    c32 tw[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tw[k] = g_twf[t * k];
+    c32 a[16];
+    c32* Tt = p.T + (size_t)pair * 65536 + (size_t)r0 * 256;     // this block's 16 rows, contiguous
+
+    if (HAS_INV) {
+        const float4* src = reinterpret_cast<const float4*>(Tt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 7, c2 = idx & 127;
+            *reinterpret_cast<float4*>(&lds[row * RP + 2 * c2]) = src[idx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = lds[g * RP + t + 16 * j];
+        __syncthreads();
+        row_fft256<true>(a, tw, lds + g * XP, t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[g * RP + t + 16 * j] = a[j];
+        __syncthreads();
+    }
+
+    // pointwise phase, 4 consecutive pixels per lane (16-B global accesses)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 6, n4 = (idx & 63) * 4;
+        const size_t off = (size_t)(r0 + row) * 256 + n4;
+        float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
+        if (HAS_INV) {
+            const float4 c01 = *reinterpret_cast<const float4*>(&lds[row * RP + n4]);
+            const float4 c23 = *reinterpret_cast<const float4*>(&lds[row * RP + n4 + 2]);
+            xa[0] = fabsf(c01.x) * p.scale; xb[0] = fabsf(c01.y) * p.scale;
+            xa[1] = fabsf(c01.z) * p.scale; xb[1] = fabsf(c01.w) * p.scale;
+            xa[2] = fabsf(c23.x) * p.scale; xb[2] = fabsf(c23.y) * p.scale;
+            xa[3] = fabsf(c23.z) * p.scale; xb[3] = fabsf(c23.w) * p.scale;
+        }
+        float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+        if (PROX != 0 || !HAS_INV) {
+            const float4 v1 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sa * 65536 + off);
+            const float4 v2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * 65536 + off);
+            za[0] = v1.x; za[1] = v1.y; za[2] = v1.z; za[3] = v1.w;
+            wa[0] = v2.x; wa[1] = v2.y; wa[2] = v2.z; wa[3] = v2.w;
+            if (has_b) {
+                const float4 v3 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sb * 65536 + off);
+                const float4 v4 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * 65536 + off);
+                zb[0] = v3.x; zb[1] = v3.y; zb[2] = v3.z; zb[3] = v3.w;
+                wb[0] = v4.x; wb[1] = v4.y; wb[2] = v4.z; wb[3] = v4.w;
+            }
+        }
+        if (PROX != 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], p.prox); prox_l1_pt(xb[q], zb[q], wb[q], p.prox); }
+                else           { prox_cnc_pt(xa[q], za[q], wa[q], p.prox); prox_cnc_pt(xb[q], zb[q], wb[q], p.prox); }
+            }
+            *reinterpret_cast<float4*>(p.z_out + (size_t)sa * 65536 + off) = make_float4(za[0], za[1], za[2], za[3]);
+            *reinterpret_cast<float4*>(p.w_out + (size_t)sa * 65536 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
+            if (has_b) {
+                *reinterpret_cast<float4*>(p.z_out + (size_t)sb * 65536 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
+                *reinterpret_cast<float4*>(p.w_out + (size_t)sb * 65536 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
+            }
+        }
+        if (WRITE_X) {
+            *reinterpret_cast<float4*>(p.x_out + (size_t)sa * 65536 + off) = make_float4(xa[0], xa[1], xa[2], xa[3]);
+            if (has_b) *reinterpret_cast<float4*>(p.x_out + (size_t)sb * 65536 + off) = make_float4(xb[0], xb[1], xb[2], xb[3]);
+        }
+        if (HAS_FWD) {
+            *reinterpret_cast<float4*>(&lds[row * RP + n4]) = make_float4(za[0] - wa[0], zb[0] - wb[0], za[1] - wa[1], zb[1] - wb[1]);
+            *reinterpret_cast<float4*>(&lds[row * RP + n4 + 2]) = make_float4(za[2] - wa[2], zb[2] - wb[2], za[3] - wa[3], zb[3] - wb[3]);
+        }
+    }
+
+    if (HAS_FWD) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = lds[g * RP + t + 16 * j];
+        __syncthreads();
+        row_fft256<false>(a, tw, lds + g * XP, t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[g * RP + t + 16 * j] = a[j];
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(Tt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 7, c2 = idx & 127;
+            dst[idx] = *reinterpret_cast<const float4*>(&lds[row * RP + 2 * c2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// columns
+// ------------------------------------------------------------------------------------------
+struct FColArgs {
+    c32* T;
+    const float4* Yh;
+    const unsigned long long* Mh;
+    float c;
+};
+
+constexpr int CP = 257;     // exchange region (c32) per column group: 514 dwords % 64 == 2
+
+template <bool INV>
+__device__ __forceinline__ void col_exchange(c32 (&a)[16], c32* region, int t) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) region[k * 16 + t] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) a[n] = region[t * 16 + n];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
+    __shared__ c32 lds[16 * CP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kl = lane & 15, t = 4 * wv + (lane >> 4);
+    const int pair = blockIdx.x / 9, m = blockIdx.x % 9;
+    const int k2 = 16 * m + kl;
+    const bool valid = k2 <= 128;
+    const int k2m = (256 - k2) & 255;
+    c32* Tp = p.T + (size_t)pair * 65536;
+    c32 tw[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tw[k] = g_twf[t * k];
+    c32 P[16], Q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (valid) {
+            P[j] = Tp[(t + 16 * j) * 256 + k2];
+            Q[j] = Tp[(t + 16 * j) * 256 + k2m];
+        } else {
+            P[j] = mk(0.f, 0.f);
+            Q[j] = mk(0.f, 0.f);
+        }
+    }
+    c32* region = lds + kl * CP;
+    fft256_head<false>(P, tw);
+    col_exchange<false>(P, region, t);
+    fft256_tail<false>(P);                       // P[j] = C[k1 = t + 16 j, k2]
+    fft256_head<true>(Q, tw);
+    col_exchange<true>(Q, region, t);
+    fft256_tail<true>(Q);                        // Q[j] = C[-k1, -k2]
+    if (valid) {
+        const unsigned long long code = p.Mh[mh_index(pair, k2, t)];
+        const float ch = 0.5f * p.c;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 yh = p.Yh[yh_index(pair, k2, j, t)];
+            const int nibv = (int)((code >> (4 * j)) & 15ull);
+            blend_pair(P[j], Q[j], mk(yh.x, yh.y), mk(yh.z, yh.w), nibv & 3, nibv >> 2, p.c, ch);
+        }
+    }
+    fft256_head<true>(P, tw);
+    col_exchange<true>(P, region, t);
+    fft256_tail<true>(P);                        // column k2 of the blended field
+    fft256_head<false>(Q, tw);
+    col_exchange<false>(Q, region, t);
+    fft256_tail<false>(Q);                       // column 256 - k2
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            Tp[(t + 16 * j) * 256 + k2] = P[j];
+            if (k2m != k2) Tp[(t + 16 * j) * 256 + k2m] = Q[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+Fused256* fused256_create(int Bmax, hipError_t* err) {
+    Fused256* f = new Fused256();
+    f->Bmax = Bmax;
+    f->np = (Bmax + 1) / 2;
+    hipError_t e = hipMalloc((void**)&f->T, (size_t)f->np * 65536 * sizeof(c32));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Yh, (size_t)f->np * F_HALF * 256 * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)f->np * F_HALF * 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        static thread_local c32 h[256];
+        for (int m = 0; m < 256; ++m) {
+            const double a = -2.0 * M_PI * (double)m / 256.0;
+            h[m] = mk((float)cos(a), (float)sin(a));
+        }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_twf), h, sizeof(h));
+    }
+    if (e != hipSuccess) {
+        fused256_destroy(f);
+        *err = e;
+        return nullptr;
+    }
+    *err = hipSuccess;
+    return f;
+}
+
+void fused256_destroy(Fused256* f) {
+    if (!f) return;
+    if (f->T) (void)hipFree(f->T);
+    if (f->Yh) (void)hipFree(f->Yh);
+    if (f->Mh) (void)hipFree(f->Mh);
+    delete f;
+}
+
+hipError_t fused256_prepare(Fused256* f, hipStream_t s, const float2* y, const uint8_t* mask_bank,
+                            const int32_t* mask_id, int B) {
+    if (B > f->Bmax) return hipErrorInvalidValue;
+    const int np = (B + 1) / 2;
+    hipLaunchKernelGGL(k_fprepare, dim3(F_HALF, np), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank,
+                       mask_id, f->Yh, f->Mh, B);
+    return hipGetLastError();
+}
+
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+static hipError_t launch_frows(hipStream_t s, int np, const FRowArgs& a) {
+    hipLaunchKernelGGL((k_frows<HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_fcols(Fused256* f, hipStream_t s, int np, float c) {
+    FColArgs a;
+    a.T = f->T; a.Yh = f->Yh; a.Mh = f->Mh; a.c = c;
+    hipLaunchKernelGGL(k_fcols, dim3(np * 9), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fused256_run(Fused256* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
+                        float dc_c, ProxParams pp) {
+    if (iters <= 0) return hipSuccess;
+    const int np = (B + 1) / 2;
+    FRowArgs a;
+    a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = z; a.w_out = w; a.x_out = x; a.B = B;
+    a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp);
+    hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) {
+        e = launch_fcols(f, s, np, dc_c);
+        if (e != hipSuccess) break;
+        const bool last = (i == iters - 1);
+        if (cnc) e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
+        else     e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+    }
+    return e;
+}
+
+hipError_t fused256_dc(Fused256* f, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c) {
+    const int np = (B + 1) / 2;
+    FRowArgs a;
+    a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = nullptr; a.w_out = nullptr; a.x_out = x; a.B = B;
+    a.scale = 1.0f / 65536.0f; a.prox = ProxCoef{};
+    hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
+    if (e == hipSuccess) e = launch_fcols(f, s, np, dc_c);
+    if (e == hipSuccess) e = launch_frows<true, 0, false, true>(s, np, a);
+    return e;
+}
+
+int fused256_kernels_per_iteration() { return 2; }
+
+}  // namespace pnp

@@ -48,6 +48,8 @@ def known_answers():
 
 
 def rel_l2(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    """||a - b|| / ||b|| in float64 / complex128 (complex inputs keep their imaginary parts)."""
+    a, b = np.asarray(a), np.asarray(b)
+    dt = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a, b = a.astype(dt), b.astype(dt)
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))

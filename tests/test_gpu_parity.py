@@ -307,11 +307,15 @@ def test_512_mixed_masks_vs_oracle(P):
     with P.Engine(H, W, Bmax=B) as eng:
         eng.upload(ys, masks, mid)
         eng.init_state()
-        eng.admm_cnc(20, 0.45, 0.5, 0.05, 64)
+        eng.admm_cnc(10, 0.45, 0.5, 0.05, 64)
         x = eng.x()
+        eng.init_state()
+        eng.admm_l1(30, 0.1, 0.015)
+        xl = eng.x()
     for b in range(B):
         y64 = ys[b].astype(np.complex64).astype(np.complex128)
-        assert rel_l2(x[b], O.admm_cnc(y64, masks[mid[b]], 20, 0.45, 0.5, 0.05, 64)) <= 1e-5
+        assert rel_l2(x[b], O.admm_cnc(y64, masks[mid[b]], 10, 0.45, 0.5, 0.05, 64)) <= 1e-5
+        assert rel_l2(xl[b], O.admm_l1(y64, masks[mid[b]], 30, 0.1, 0.015)) <= 1e-5
 
 
 def test_run_is_resumable_and_deterministic(P, golden_inputs):
