@@ -27,8 +27,12 @@ struct c32 {
 PNP_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
 PNP_HD c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
 PNP_HD c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
-PNP_HD c32 mul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-PNP_HD c32 mulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a*conj(b)
+// The library is compiled with -ffp-contract=off and every fused multiply-add is written out, so
+// the rounding sequence is fixed by this source and identical in every kernel instantiation
+// (bit-identical results whether a run is split into several calls or not) and on the host.
+PNP_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PNP_HD c32 mul(c32 a, c32 b) { return mk(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
+PNP_HD c32 mulc(c32 a, c32 b) { return mk(fma_(a.x, b.x, a.y * b.y), fma_(a.y, b.x, -(a.x * b.y))); }   // a*conj(b)
 template <bool INV> PNP_HD c32 tmul(c32 a, c32 w) { return INV ? mulc(a, w) : mul(a, w); }
 // multiply by -i (forward) / +i (inverse)
 template <bool INV> PNP_HD c32 rot(c32 a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
@@ -106,7 +110,7 @@ PNP_HD void prox_l1_pt(float x, float& z, float& w, const ProxCoef& p) {
 PNP_HD void prox_cnc_pt(float x, float& z, float& w, const ProxCoef& p) {
     const float u = x + w;
     const float cz = z < -p.ib ? -p.ib : (z > p.ib ? p.ib : z);   // z - soft(z, 1/b)
-    const float t = p.c1 * z + p.c2 * u + p.c3 * cz;
+    const float t = fma_(p.c1, z, fma_(p.c2, u, p.c3 * cz));
     z = soft_thr(t, p.thr);
     w = u - z;
 }
@@ -122,10 +126,10 @@ PNP_HD void prox_cnc_pt(float x, float& z, float& w, const ProxCoef& p) {
 PNP_HD void blend_pair(c32& P, c32& Q, c32 yha, c32 yhb, int ma, int mb, float c, float ch) {
     const float sx = P.x + Q.x, sy = P.y - Q.y;     // P + conj Q
     const float dx = P.x - Q.x, dy = P.y + Q.y;     // P - conj Q
-    const float Aa = 0.5f - 0.5f * ch * (float)ma;  // (1 - c*Mh_a)/2
-    const float Ab = 0.5f - 0.5f * ch * (float)mb;
-    const float xax = Aa * sx + c * yha.x, xay = Aa * sy + c * yha.y;
-    const float xbx = Ab * dy + c * yhb.x, xby = -Ab * dx + c * yhb.y;
+    const float Aa = fma_(-0.5f * ch, (float)ma, 0.5f);  // (1 - c*Mh_a)/2
+    const float Ab = fma_(-0.5f * ch, (float)mb, 0.5f);
+    const float xax = fma_(Aa, sx, c * yha.x), xay = fma_(Aa, sy, c * yha.y);
+    const float xbx = fma_(Ab, dy, c * yhb.x), xby = fma_(-Ab, dx, c * yhb.y);
     P = mk(xax - xby, xay + xbx);
     Q = mk(xax + xby, xbx - xay);
 }

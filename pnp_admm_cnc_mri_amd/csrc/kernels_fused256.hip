@@ -21,6 +21,7 @@
 #include "internal.h"
 #include "fused_layout.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace pnp {
 
@@ -83,6 +84,11 @@ struct FRowArgs {
     ProxCoef prox;
 };
 
+// physical column of k-space column k inside a row of T: mirrored columns sit side by side so the
+// column kernel moves {C[r][q], C[r][256-q]} as ONE aligned 16-byte access:
+//   [0]=col 0, [1]=col 128, [2q]=col q, [2q+1]=col 256-q   (q = 1..127)
+__device__ __forceinline__ int phi(int k) { return k < 128 ? 2 * k : (k == 128 ? 1 : 513 - 2 * k); }
+
 constexpr int RP = 272;    // staging pitch (c32) of a row in LDS: 272 % 32 == 16 -> two rows per
                            // 32-lane ds_read_b64 group land on disjoint bank halves
 constexpr int XP = 289;    // exchange region per 16-lane group, runs of 17 (289 % 32 == 1)
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = lds[g * RP + t + 16 * j];
+        for (int j = 0; j < 16; ++j) a[j] = lds[g * RP + phi(t + 16 * j)];
         __syncthreads();
         row_fft256<true>(a, tw, lds + g * XP, t);
 #pragma unroll
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
         __syncthreads();
         row_fft256<false>(a, tw, lds + g * XP, t);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) lds[g * RP + t + 16 * j] = a[j];
+        for (int j = 0; j < 16; ++j) lds[g * RP + phi(t + 16 * j)] = a[j];
         __syncthreads();
         float4* dst = reinterpret_cast<float4*>(Tt);
 #pragma unroll
@@ -226,9 +232,11 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kl = lane & 15, t = 4 * wv + (lane >> 4);
     const int pair = blockIdx.x / 9, m = blockIdx.x % 9;
-    const int k2 = 16 * m + kl;
-    const bool valid = k2 <= 128;
-    const int k2m = (256 - k2) & 255;
+    // tiles 0..7: column pairs q = 16 m + kl (q >= 1) = physical columns (2q, 2q+1);
+    // tile 8: the two self-mirrored columns 0 and 128 (physical 0 and 1), one lane group each.
+    const bool self = (m == 8);
+    const int k2 = self ? (kl == 0 ? 0 : 128) : 16 * m + kl;
+    const bool valid = self ? (kl < 2) : (k2 >= 1);
     c32* Tp = p.T + (size_t)pair * 65536;
     c32 tw[16];
 #pragma unroll
@@ -236,12 +244,18 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
     c32 P[16], Q[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+        P[j] = mk(0.f, 0.f);
+        Q[j] = mk(0.f, 0.f);
         if (valid) {
-            P[j] = Tp[(t + 16 * j) * 256 + k2];
-            Q[j] = Tp[(t + 16 * j) * 256 + k2m];
-        } else {
-            P[j] = mk(0.f, 0.f);
-            Q[j] = mk(0.f, 0.f);
+            const c32* rowp = Tp + (t + 16 * j) * 256;
+            if (self) {
+                P[j] = rowp[kl];
+                Q[j] = P[j];
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(rowp + 2 * k2);
+                P[j] = mk(v.x, v.y);
+                Q[j] = mk(v.z, v.w);
+            }
         }
     }
     c32* region = lds + kl * CP;
@@ -270,8 +284,9 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
     if (valid) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            Tp[(t + 16 * j) * 256 + k2] = P[j];
-            if (k2m != k2) Tp[(t + 16 * j) * 256 + k2m] = Q[j];
+            c32* rowp = Tp + (t + 16 * j) * 256;
+            if (self) rowp[kl] = P[j];
+            else *reinterpret_cast<float4*>(rowp + 2 * k2) = make_float4(P[j].x, P[j].y, Q[j].x, Q[j].y);
         }
     }
 }
@@ -326,27 +341,53 @@ static hipError_t launch_frows(hipStream_t s, int np, const FRowArgs& a) {
     return hipGetLastError();
 }
 
-static hipError_t launch_fcols(Fused256* f, hipStream_t s, int np, float c) {
+static hipError_t launch_fcols(Fused256* f, hipStream_t s, int pair0, int np, float c) {
     FColArgs a;
-    a.T = f->T; a.Yh = f->Yh; a.Mh = f->Mh; a.c = c;
+    a.T = f->T + (size_t)pair0 * 65536;
+    a.Yh = f->Yh + (size_t)pair0 * F_HALF * 256;
+    a.Mh = f->Mh + (size_t)pair0 * F_HALF * 16;
+    a.c = c;
     hipLaunchKernelGGL(k_fcols, dim3(np * 9), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+// Slices are independent, so a K-iteration run may finish K iterations on one chunk of slices
+// before touching the next: with chunk*(z,w,T,Yh) <= the 256 MiB Infinity Cache the loop's
+// working set stays on die.  0 = no chunking.  (PNP_FUSED_CHUNK overrides, for experiments.)
+static int fused_chunk(int B) {
+    static int env = -1;
+    if (env < 0) {
+        const char* e = getenv("PNP_FUSED_CHUNK");
+        env = e ? atoi(e) : 0;
+        if (env < 0) env = 0;
+    }
+    int c = env > 0 ? env : B;
+    c &= ~1;
+    if (c < 2) c = 2;
+    return c;
 }
 
 hipError_t fused256_run(Fused256* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
                         float dc_c, ProxParams pp) {
     if (iters <= 0) return hipSuccess;
-    const int np = (B + 1) / 2;
-    FRowArgs a;
-    a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = z; a.w_out = w; a.x_out = x; a.B = B;
-    a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp);
-    hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
-    for (int i = 0; i < iters && e == hipSuccess; ++i) {
-        e = launch_fcols(f, s, np, dc_c);
-        if (e != hipSuccess) break;
-        const bool last = (i == iters - 1);
-        if (cnc) e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
-        else     e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+    const int chunk = fused_chunk(B);
+    hipError_t e = hipSuccess;
+    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk) {
+        const int Bc = (B - c0 < chunk) ? (B - c0) : chunk;
+        const int np = (Bc + 1) / 2, pair0 = c0 / 2;
+        const size_t so = (size_t)c0 * 65536;
+        FRowArgs a;
+        a.T = f->T + (size_t)pair0 * 65536;
+        a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
+        a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp);
+        e = launch_frows<false, 0, true, false>(s, np, a);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) {
+            e = launch_fcols(f, s, pair0, np, dc_c);
+            if (e != hipSuccess) break;
+            const bool last = (i == iters - 1);
+            if (cnc) e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
+            else     e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+        }
     }
     return e;
 }
@@ -357,7 +398,7 @@ hipError_t fused256_dc(Fused256* f, hipStream_t s, const float* z, const float* 
     a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = nullptr; a.w_out = nullptr; a.x_out = x; a.B = B;
     a.scale = 1.0f / 65536.0f; a.prox = ProxCoef{};
     hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
-    if (e == hipSuccess) e = launch_fcols(f, s, np, dc_c);
+    if (e == hipSuccess) e = launch_fcols(f, s, 0, np, dc_c);
     if (e == hipSuccess) e = launch_frows<true, 0, false, true>(s, np, a);
     return e;
 }

@@ -34,10 +34,10 @@ hipError_t upload_twiddles() {
 }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {   // a * conj(b)
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -98,7 +98,7 @@ __device__ __forceinline__ void prox_l1(float x, float& z, float& w, const ProxP
 __device__ __forceinline__ void prox_cnc(float x, float& z, float& w, const ProxParams& p) {
     const float u = x + w;
     const float clipz = fminf(fmaxf(z, -p.ib), p.ib);          // z - soft(z, 1/b)
-    const float t = p.c1 * z + p.c2 * u + p.c3 * clipz;
+    const float t = fmaf(p.c1, z, fmaf(p.c2, u, p.c3 * clipz));
     z = soft(t, p.thr);
     w = u - z;
 }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_cols(ColArgs p, int W) {
             float2 X = cur[c * P + r];
             const bool m = mask[g] != 0;
             if (MID == MID_BLEND) {
-                if (m) { const float2 yv = yb[g]; X.x += (yv.x - X.x) * p.c; X.y += (yv.y - X.y) * p.c; }
+                if (m) { const float2 yv = yb[g]; X.x = fmaf(yv.x - X.x, p.c, X.x); X.y = fmaf(yv.y - X.y, p.c, X.y); }
             } else if (MID == MID_MASK) {
                 if (!m) X = make_float2(0.f, 0.f);
             } else if (MID == MID_RESID) {
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void k_combine(const float4* z, const float4* 
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 zv = z[i], xv = x[i], wv = w[i], sv = sd[i];
         float4 o;
+        // S6:301 evaluated left to right in float32 like the reference's torch expression
         o.x = c1 * zv.x + c2 * (xv.x + wv.x) + c3 * (zv.x - sv.x);
         o.y = c1 * zv.y + c2 * (xv.y + wv.y) + c3 * (zv.y - sv.y);
         o.z = c1 * zv.z + c2 * (xv.z + wv.z) + c3 * (zv.z - sv.z);
