@@ -20,6 +20,8 @@
  *   - all kernels are asynchronous on the ctx stream (pnp_set_stream); only pnp_sync,
  *     host-side downloads and pnp_timer_stop block.
  *   - one ctx per device per host thread; a ctx is not re-entrant.
+ *   - hyper-parameters (alpha, lambda1, reo, b, thresholds) are C doubles, as the Python floats of
+ *     the reference are; derived coefficients are formed in double and rounded to float once.
  *   - H, W in {256, 512}.  B <= Bmax.
  */
 #ifndef PNP_MRI_H
@@ -37,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   1
+#define PNP_ABI_VERSION   2
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -81,11 +83,11 @@ int pnp_get_state(pnp_ctx* ctx, float* z, float* w, int on_device);
 
 /* ---- whole loops on the ctx-owned state (no host sync inside) ----------------------------- */
 /* ADMM_L1 main loop, S1:111-126:  x = dc(z,w); z = soft(x+w, reo*lambda1); w += x - z. */
-int pnp_admm_l1_run(pnp_ctx* ctx, int iters, float lambda1, float reo);
+int pnp_admm_l1_run(pnp_ctx* ctx, int iters, double lambda1, double reo);
 /* ADMM_CNC main loop, S4:115-132: x = dc(z,w); s = soft(z,1/b);
  * t = (1-alpha) z + alpha (x+w) + alpha*reo*lambda1*b (z-s); z = soft(t, alpha*reo*lambda1);
  * w += x - z. */
-int pnp_admm_cnc_run(pnp_ctx* ctx, int iters, float alpha, float lambda1, float reo, float b);
+int pnp_admm_cnc_run(pnp_ctx* ctx, int iters, double alpha, double lambda1, double reo, double b);
 /* x of the last iteration ([B][H][W] float32) -- what the solvers return (S4:138). */
 int pnp_download_x(pnp_ctx* ctx, float* x, int on_device);
 
@@ -93,15 +95,15 @@ int pnp_download_x(pnp_ctx* ctx, float* x, int on_device);
 /* x-update / data-consistency solve, S4:119-124 == S6:266-271:
  *   X = fft2(z - w); X[mask] = (La2*X[mask] + y[mask])/(1+La2), La2 = 1/(2 reo);
  *   x = |Re ifft2(X)|.      z, w, x: [B][H][W] float32 device pointers (x may alias neither). */
-int pnp_dc_step(pnp_ctx* ctx, const float* z_dev, const float* w_dev, float* x_dev, float reo);
+int pnp_dc_step(pnp_ctx* ctx, const float* z_dev, const float* w_dev, float* x_dev, double reo);
 /* z = soft(x + w, thr); w = w + x - z                                           (S1:123,126) */
-int pnp_prox_l1_dual(pnp_ctx* ctx, const float* x_dev, float* z_dev, float* w_dev, float thr);
+int pnp_prox_l1_dual(pnp_ctx* ctx, const float* x_dev, float* z_dev, float* w_dev, double thr);
 /* CNC z-update + dual update                                                 (S4:127-129,132) */
 int pnp_prox_cnc_dual(pnp_ctx* ctx, const float* x_dev, float* z_dev, float* w_dev,
-                      float alpha, float lambda1, float reo, float b);
+                      double alpha, double lambda1, double reo, double b);
 /* t = (1-alpha) z + alpha (x+w) + alpha*reo*lambda1*b (z - s)                       (S6:301) */
 int pnp_cnc_combine(pnp_ctx* ctx, const float* z_dev, const float* x_dev, const float* w_dev,
-                    const float* s_dev, float* t_dev, float alpha, float lambda1, float reo, float b);
+                    const float* s_dev, float* t_dev, double alpha, double lambda1, double reo, double b);
 /* t = x + w  (the denoiser input of PNP_ADMM_L1_D, S3:290) */
 int pnp_add(pnp_ctx* ctx, const float* a_dev, const float* b_dev, float* out_dev);
 /* w = w + x - z, then x,z,w <- clamp(.,0,1)                                 (S6:305-308) */

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Golden vectors for the PnP entry points, from the UNMODIFIED reference scripts
+("【6】PNP_ADMM_CNC_D .py", "【3】PNP_ADMM_L1_D  .py") run on CPU in the build container.
+
+TEST INFRASTRUCTURE (see oracle/make_golden.py for how the scripts are run).  The reference ships
+no weights (model_zoo/README.md), so the nets get deterministic synthetic weights from
+pnp_admm_cnc_mri_amd.denoisers.seeded_state_dict -- saved as model_zoo/<name>.pth in the scratch
+dir and loaded by the reference's own model classes with strict=True, which also proves that the
+build's module declarations have KAIR's exact state_dict keys and shapes.
+
+ircnn_gray cannot be generated: the reference's bank switch uses `np.int` (S6:290), removed in
+NumPy >= 1.24, so that branch raises under the NumPy 2.2.6 of this image.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import make_golden as MG                                   # noqa: E402
+from pnp_admm_cnc_mri_amd import denoisers as D           # noqa: E402
+
+S3 = os.path.join(MG.REF, '【3】PNP_ADMM_L1_D  .py')
+S6 = os.path.join(MG.REF, '【6】PNP_ADMM_CNC_D .py')
+NAMES = ['drunet_gray', 'ffdnet_gray', 'fdncnn_gray', 'dncnn_15', 'dncnn_25']
+SEEDS = {n: 1000 + i for i, n in enumerate(NAMES)}
+ITERS = 3
+
+
+def main():
+    MG.install_shims()
+    d = MG.scratch_dir()
+    os.chdir(d)
+    os.makedirs('model_zoo')
+    shapes = {}
+    for n in NAMES:
+        net, _, _ = D.build(n)
+        sd = D.seeded_state_dict(net, SEEDS[n])
+        torch.save(sd, os.path.join('model_zoo', n + '.pth'))
+        shapes[n] = {k: list(v.shape) for k, v in sd.items()}
+    torch.set_num_threads(8)
+    arrays, known = {}, {'numpy': np.__version__, 'torch': torch.__version__, 'iters': ITERS, 'seeds': SEEDS,
+                         'note': 'x after %d iterations, 05.png, Q_Random30, committed presets otherwise' % ITERS}
+
+    def line(lines):
+        return [l for l in lines if 'PSNR' in l and '05.png' in l][-1]
+
+    # ---- S6: main runs drunet_gray (CNC_D) and the dncnn_25/dncnn_15 pair ----------------------
+    g, lines, _ = MG.run_script(S6, ['--iter_num', str(ITERS)], 'Set1_dn_drunet_gray')
+    arrays['cnc_d_drunet_gray'] = np.asarray(g['out1'], np.float32)
+    arrays['cnc_dncnn_pair'] = np.asarray(g['out2'], np.float32)
+    known['cnc_d_drunet_gray'] = line(lines)
+    opts = {'ffdnet_gray': g['PNP_ADMM_CNC_D_opts2'], 'fdncnn_gray': g['PNP_ADMM_CNC_D_opts1']}
+    for n in ('ffdnet_gray', 'fdncnn_gray'):
+        cap = MG._Capture('Set1_dn_' + n)
+        with contextlib.redirect_stdout(io.StringIO()):
+            o, _ = g['PNP_ADMM_CNC_D'](n, g['mask'][0], g['noises'], **opts[n])
+        arrays['cnc_d_' + n] = np.asarray(o[0], np.float32)
+        known['cnc_d_' + n] = line(cap.lines)
+        known['cnc_d_' + n + '_opts'] = {k: float(v) for k, v in opts[n].items()}
+    known['cnc_d_drunet_gray_opts'] = {k: float(v) for k, v in g['PNP_ADMM_CNC_D_opts4'].items()}
+    known['cnc_dncnn_pair_opts'] = {k: float(v) for k, v in g['PNP_ADMM_CNC_DnCNN_opts'].items()}
+
+    # ---- S3: main runs drunet_gray (x8 augmentation cycles with i % 8) --------------------------
+    g, lines, _ = MG.run_script(S3, ['--iter_num', str(ITERS)], 'Set1_dn_drunet_gray')
+    arrays['l1_d_drunet_gray'] = np.asarray(g['out'][0], np.float32)
+    o3 = {'ffdnet_gray': g['PNP_ADMM_L1_D_opts3'], 'dncnn_15': g['PNP_ADMM_L1_D_opts2'], 'fdncnn_gray': g['PNP_ADMM_L1_D_opts1']}
+    known['l1_d_drunet_gray_opts'] = {k: float(v) for k, v in g['PNP_ADMM_L1_D_opts5'].items()}
+    for n in ('ffdnet_gray', 'dncnn_15', 'fdncnn_gray'):
+        with contextlib.redirect_stdout(io.StringIO()):
+            o = g['PNP_ADMM_L1_D'](n, g['mask'][0], g['noises'], **o3[n])
+        arrays['l1_d_' + n] = np.asarray(o[0], np.float32)
+        known['l1_d_' + n + '_opts'] = {k: float(v) for k, v in o3[n].items()}
+
+    for k, v in arrays.items():
+        assert v.shape == (256, 256) and np.isfinite(v).all(), k
+        known[k + '_sum'] = float(v.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(MG.GOLD, 'pnp_set1_05.npz'), **arrays)
+    with open(os.path.join(MG.GOLD, 'pnp_known.json'), 'w') as f:
+        json.dump({'known': known, 'state_dict_shapes': shapes}, f, indent=1, sort_keys=True)
+    print(json.dumps(known, indent=1, sort_keys=True))
+
+
+if __name__ == '__main__':
+    main()

@@ -33,13 +33,13 @@ SIGNATURES = {
     'pnp_init_state': (C.c_int, [ctx_p]),
     'pnp_set_state': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
     'pnp_get_state': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
-    'pnp_admm_l1_run': (C.c_int, [ctx_p, C.c_int, C.c_float, C.c_float]),
-    'pnp_admm_cnc_run': (C.c_int, [ctx_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    'pnp_admm_l1_run': (C.c_int, [ctx_p, C.c_int, C.c_double, C.c_double]),
+    'pnp_admm_cnc_run': (C.c_int, [ctx_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     'pnp_download_x': (C.c_int, [ctx_p, _vp, C.c_int]),
-    'pnp_dc_step': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_float]),
-    'pnp_prox_l1_dual': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_float]),
-    'pnp_prox_cnc_dual': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float]),
-    'pnp_cnc_combine': (C.c_int, [ctx_p, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+    'pnp_dc_step': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_double]),
+    'pnp_prox_l1_dual': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_double]),
+    'pnp_prox_cnc_dual': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double]),
+    'pnp_cnc_combine': (C.c_int, [ctx_p, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double]),
     'pnp_add': (C.c_int, [ctx_p, _vp, _vp, _vp]),
     'pnp_dual_clamp': (C.c_int, [ctx_p, _vp, _vp, _vp]),
     'pnp_fft2_fwd': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
@@ -54,7 +54,7 @@ SIGNATURES = {
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

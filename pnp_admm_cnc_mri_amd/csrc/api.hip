@@ -280,9 +280,9 @@ static int generic_iteration(pnp_ctx* c, const float* z_in, const float* w_in, R
     return PNP_OK;
 }
 
-static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, float reo) {
+static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, double reo) {
     if (iters < 0) return fail(PNP_E_ARG, "iters must be >= 0");
-    if (!(reo > 0.0f)) return fail(PNP_E_ARG, "reo must be > 0");
+    if (!(reo > 0.0)) return fail(PNP_E_ARG, "reo must be > 0");
     if (iters == 0) return PNP_OK;
     const float cdc = dc_coeff(reo);
     if (use_fused(c)) {
@@ -298,14 +298,14 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, float
     return PNP_OK;
 }
 
-int pnp_admm_l1_run(pnp_ctx* c, int iters, float lambda1, float reo) {
+int pnp_admm_l1_run(pnp_ctx* c, int iters, double lambda1, double reo) {
     CTX(c); NEED_PROBLEM(c);
     return run_loop(c, iters, false, make_prox_l1(lambda1, reo), reo);
 }
 
-int pnp_admm_cnc_run(pnp_ctx* c, int iters, float alpha, float lambda1, float reo, float b) {
+int pnp_admm_cnc_run(pnp_ctx* c, int iters, double alpha, double lambda1, double reo, double b) {
     CTX(c); NEED_PROBLEM(c);
-    if (!(b > 0.0f)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: b must be > 0");
+    if (!(b > 0.0)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: b must be > 0");
     return run_loop(c, iters, true, make_prox_cnc(alpha, lambda1, reo, b), reo);
 }
 
@@ -316,10 +316,10 @@ int pnp_download_x(pnp_ctx* c, float* x, int on_device) {
     return copy_out(c, x, c->x, (size_t)c->B * c->N * sizeof(float), on_device);
 }
 
-int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, float reo) {
+int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo) {
     CTX(c); NEED_PROBLEM(c);
     if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
-    if (!(reo > 0.0f)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
+    if (!(reo > 0.0)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
     if (use_fused(c)) {
         HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
         return PNP_OK;
@@ -327,28 +327,28 @@ int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, float reo)
     return generic_iteration(c, z, w, EPI_ABS_REAL, ProxParams{}, dc_coeff(reo), x, nullptr, nullptr);
 }
 
-int pnp_prox_l1_dual(pnp_ctx* c, const float* x, float* z, float* w, float thr) {
+int pnp_prox_l1_dual(pnp_ctx* c, const float* x, float* z, float* w, double thr) {
     CTX(c); NEED_PROBLEM(c);
     if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_prox_l1_dual: null pointer");
-    ProxParams p{}; p.thr = thr;
+    ProxParams p{}; p.thr = (float)thr;
     HIPCHK(launch_prox(c->stream, false, x, z, w, p, (size_t)c->B * c->N));
     return PNP_OK;
 }
 
-int pnp_prox_cnc_dual(pnp_ctx* c, const float* x, float* z, float* w, float alpha, float lambda1, float reo, float b) {
+int pnp_prox_cnc_dual(pnp_ctx* c, const float* x, float* z, float* w, double alpha, double lambda1, double reo, double b) {
     CTX(c); NEED_PROBLEM(c);
     if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: null pointer");
-    if (!(b > 0.0f)) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: b must be > 0");
+    if (!(b > 0.0)) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: b must be > 0");
     HIPCHK(launch_prox(c->stream, true, x, z, w, make_prox_cnc(alpha, lambda1, reo, b), (size_t)c->B * c->N));
     return PNP_OK;
 }
 
 int pnp_cnc_combine(pnp_ctx* c, const float* z, const float* x, const float* w, const float* s, float* t,
-                    float alpha, float lambda1, float reo, float b) {
+                    double alpha, double lambda1, double reo, double b) {
     CTX(c); NEED_PROBLEM(c);
     if (!z || !x || !w || !s || !t) return fail(PNP_E_ARG, "pnp_cnc_combine: null pointer");
-    HIPCHK(launch_combine(c->stream, z, x, w, s, t, (float)(1.0 - (double)alpha), alpha,
-                          (float)((double)alpha * reo * lambda1 * b), (size_t)c->B * c->N));
+    HIPCHK(launch_combine(c->stream, z, x, w, s, t, (float)(1.0 - alpha), (float)alpha,
+                          (float)(alpha * reo * lambda1 * b), (size_t)c->B * c->N));
     return PNP_OK;
 }
 

@@ -1,0 +1,301 @@
+"""Denoiser networks of the PnP solvers as plain PyTorch-ROCm modules (the north star keeps the
+CNN forward pass in PyTorch/MIOpen: MFMA work lives only inside these conv layers).
+
+Own declarations of the five architectures the reference instantiates, with KAIR's state_dict
+key names so real `model_zoo/*.pth` files load with `strict=True`:
+
+    DnCNN   models/network_dncnn.py:36-67    model.{0,2,..,32}.{weight,bias}   17 conv, x - n
+    FDnCNN  models/network_dncnn.py:120-141  model.{0,2,..,38}                 20 conv, 2-ch in
+    IRCNN   models/network_dncnn.py:70-109   model.{0,2,..,12}                 7 dilated conv, x - n
+    FFDNet  models/network_ffdnet.py:31-73   model.{0,2,..,28}                 unshuffle/15 conv/shuffle
+    UNetRes models/network_unet.py:76-136    m_head, m_down{1,2,3}, m_body, m_up{3,2,1}, m_tail (DRUNet)
+
+plus the dispatch `denoising_step` (S6:18-67 == S3:19-68), the inference wrapper `test_mode`
+(utils/utils_model.py:12-109; modes 0 and 2 are the ones the solvers reach), `augment_img_tensor4`
+(utils/utils_image.py:333-349) and a deterministic weight generator for parity tests (the
+reference ships no weights: model_zoo/README.md).
+"""
+import hashlib
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv_stack(in_nc, out_nc, nc, nb, dilations=None):
+    """[Conv3x3, ReLU] * (nb-1) + Conv3x3 as one nn.Sequential (conv at the even indices)."""
+    L = []
+    for i in range(nb):
+        ci = in_nc if i == 0 else nc
+        co = out_nc if i == nb - 1 else nc
+        d = 1 if dilations is None else dilations[i]
+        L.append(nn.Conv2d(ci, co, 3, 1, d, dilation=d, bias=True))
+        if i != nb - 1:
+            L.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*L)
+
+
+class DnCNN(nn.Module):
+    def __init__(self, in_nc=1, out_nc=1, nc=64, nb=17):
+        super().__init__()
+        self.model = _conv_stack(in_nc, out_nc, nc, nb)
+
+    def forward(self, x):
+        return x - self.model(x)
+
+
+class FDnCNN(nn.Module):
+    def __init__(self, in_nc=2, out_nc=1, nc=64, nb=20):
+        super().__init__()
+        self.model = _conv_stack(in_nc, out_nc, nc, nb)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class IRCNN(nn.Module):
+    def __init__(self, in_nc=1, out_nc=1, nc=64):
+        super().__init__()
+        self.model = _conv_stack(in_nc, out_nc, nc, 7, dilations=[1, 2, 3, 4, 3, 2, 1])
+
+    def forward(self, x):
+        return x - self.model(x)
+
+
+class FFDNet(nn.Module):
+    def __init__(self, in_nc=1, out_nc=1, nc=64, nb=15):
+        super().__init__()
+        self.model = _conv_stack(in_nc * 4 + 1, out_nc * 4, nc, nb)
+
+    def forward(self, x, sigma):
+        """sigma: [B,1,1,1] (or [1,1,1,1], broadcast over the batch -- the reference's
+        `sigma.repeat(1, 1, H/2, W/2)` only works for B = 1, models/network_ffdnet.py:67)."""
+        h, w = x.shape[-2:]
+        x = F.pad(x, (0, int(math.ceil(w / 2) * 2 - w), 0, int(math.ceil(h / 2) * 2 - h)), mode='replicate')
+        x = F.pixel_unshuffle(x, 2)
+        m = sigma.to(x.dtype).expand(x.shape[0], 1, x.shape[-2], x.shape[-1])
+        x = self.model(torch.cat((x, m), 1))
+        x = F.pixel_shuffle(x, 2)
+        return x[..., :h, :w]
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, nc):
+        super().__init__()
+        self.res = nn.Sequential(nn.Conv2d(nc, nc, 3, 1, 1, bias=False), nn.ReLU(inplace=True),
+                                 nn.Conv2d(nc, nc, 3, 1, 1, bias=False))
+
+    def forward(self, x):
+        return x + self.res(x)
+
+
+class UNetRes(nn.Module):
+    """DRUNet: 4 scales, 4 residual blocks each, stride-2 conv down, 2x2 transposed conv up, no bias."""
+
+    def __init__(self, in_nc=2, out_nc=1, nc=(64, 128, 256, 512), nb=4):
+        super().__init__()
+        rb = lambda c: [_ResBlock(c) for _ in range(nb)]
+        self.m_head = nn.Conv2d(in_nc, nc[0], 3, 1, 1, bias=False)
+        self.m_down1 = nn.Sequential(*rb(nc[0]), nn.Conv2d(nc[0], nc[1], 2, 2, 0, bias=False))
+        self.m_down2 = nn.Sequential(*rb(nc[1]), nn.Conv2d(nc[1], nc[2], 2, 2, 0, bias=False))
+        self.m_down3 = nn.Sequential(*rb(nc[2]), nn.Conv2d(nc[2], nc[3], 2, 2, 0, bias=False))
+        self.m_body = nn.Sequential(*rb(nc[3]))
+        self.m_up3 = nn.Sequential(nn.ConvTranspose2d(nc[3], nc[2], 2, 2, 0, bias=False), *rb(nc[2]))
+        self.m_up2 = nn.Sequential(nn.ConvTranspose2d(nc[2], nc[1], 2, 2, 0, bias=False), *rb(nc[1]))
+        self.m_up1 = nn.Sequential(nn.ConvTranspose2d(nc[1], nc[0], 2, 2, 0, bias=False), *rb(nc[0]))
+        self.m_tail = nn.Conv2d(nc[0], out_nc, 3, 1, 1, bias=False)
+
+    def forward(self, x0):
+        x1 = self.m_head(x0)
+        x2 = self.m_down1(x1)
+        x3 = self.m_down2(x2)
+        x4 = self.m_down3(x3)
+        x = self.m_body(x4)
+        x = self.m_up3(x + x4)
+        x = self.m_up2(x + x3)
+        x = self.m_up1(x + x2)
+        return self.m_tail(x + x1)
+
+
+# ----------------------------------------------------------------------------------------------
+# model construction by name, as the substring switch of S6:129-217 / S3:122-215 does it
+# ----------------------------------------------------------------------------------------------
+def family(model_name):
+    if 'dncnn' in model_name and 'fdncnn' not in model_name:
+        return 'dncnn'
+    for f in ('fdncnn', 'drunet', 'ircnn', 'ffdnet'):
+        if f in model_name:
+            return f
+    raise ValueError('unknown denoiser %r' % model_name)
+
+
+def build(model_name):
+    """-> (module, noise_level_model, uses_sigma_schedule).  Constants: S6:131,150,167,186,201."""
+    fam = family(model_name)
+    if fam == 'dncnn':
+        nb = 20 if model_name in ['dncnn_gray_blind', 'dncnn_color_blind', 'dncnn3'] else 17      # S6:133-136
+        return DnCNN(1, 1, 64, nb), 15, False
+    if fam == 'fdncnn':
+        return FDnCNN(2, 1, 64, 20), 15, False
+    if fam == 'drunet':
+        return UNetRes(2, 1, (64, 128, 256, 512), 4), 15 / 255.0, True
+    if fam == 'ircnn':
+        return IRCNN(1, 1, 64), 15 / 255.0, True
+    return FFDNet(1, 1, 64, 15), 15, False
+
+
+def seeded_state_dict(module, seed=0, gain=1.0):
+    """Deterministic synthetic weights, generated per tensor from a NumPy RNG keyed by
+    (seed, state_dict key) -- identical wherever it is run, independent of torch's RNG.
+    He-scaled normal weights (x gain), small biases, last layer damped so outputs stay O(input)."""
+    sd = module.state_dict()
+    keys = list(sd.keys())
+    last_w = [k for k in keys if k.endswith('weight')][-1]
+    out = {}
+    for k in keys:
+        v = sd[k]
+        h = int.from_bytes(hashlib.sha256(('%d:%s' % (seed, k)).encode()).digest()[:8], 'little')
+        rng = np.random.default_rng(h)
+        if k.endswith('weight'):
+            fan_in = int(np.prod(v.shape[1:])) if v.dim() > 1 else int(v.shape[0])
+            std = gain * math.sqrt(2.0 / fan_in) * (0.3 if k == last_w else 1.0)
+            if '.res.2.' in k:
+                std *= 0.1            # residual branches near identity: keeps deep random nets well conditioned
+            a = rng.standard_normal(tuple(v.shape)).astype(np.float32) * np.float32(std)
+        else:
+            a = rng.standard_normal(tuple(v.shape)).astype(np.float32) * np.float32(0.01)
+        out[k] = torch.from_numpy(a)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# inference helpers
+# ----------------------------------------------------------------------------------------------
+def augment_img_tensor4(img, mode=0):
+    """utils/utils_image.py:333-349."""
+    if mode == 0:
+        return img
+    if mode == 1:
+        return img.rot90(1, [2, 3]).flip([2])
+    if mode == 2:
+        return img.flip([2])
+    if mode == 3:
+        return img.rot90(3, [2, 3])
+    if mode == 4:
+        return img.rot90(2, [2, 3]).flip([2])
+    if mode == 5:
+        return img.rot90(1, [2, 3])
+    if mode == 6:
+        return img.rot90(2, [2, 3])
+    if mode == 7:
+        return img.rot90(3, [2, 3]).flip([2])
+    raise ValueError(mode)
+
+
+def test_split_fn(model, L, refield=32, min_size=256, sf=1, modulo=1):
+    """utils/utils_model.py:76-109: whole image when h*w <= min_size^2 (padded to `modulo`),
+    otherwise four overlapping quadrants stitched back (recursively beyond 4*min_size^2)."""
+    h, w = L.shape[-2:]
+    if h * w <= min_size ** 2:
+        L = F.pad(L, (0, int(math.ceil(w / modulo) * modulo - w), 0, int(math.ceil(h / modulo) * modulo - h)), mode='replicate')
+        return model(L)[..., :h * sf, :w * sf]
+    top = slice(0, (h // 2 // refield + 1) * refield)
+    bottom = slice(h - (h // 2 // refield + 1) * refield, h)
+    left = slice(0, (w // 2 // refield + 1) * refield)
+    right = slice(w - (w // 2 // refield + 1) * refield, w)
+    Ls = [L[..., top, left], L[..., top, right], L[..., bottom, left], L[..., bottom, right]]
+    if h * w <= 4 * (min_size ** 2):
+        Es = [model(Ls[i].contiguous()) for i in range(4)]
+    else:
+        Es = [test_split_fn(model, Ls[i], refield, min_size, sf, modulo) for i in range(4)]
+    b, c = Es[0].shape[:2]
+    E = torch.zeros(b, c, sf * h, sf * w, dtype=L.dtype, device=L.device)
+    E[..., :h // 2 * sf, :w // 2 * sf] = Es[0][..., :h // 2 * sf, :w // 2 * sf]
+    E[..., :h // 2 * sf, w // 2 * sf:w * sf] = Es[1][..., :h // 2 * sf, (-w + w // 2) * sf:]
+    E[..., h // 2 * sf:h * sf, :w // 2 * sf] = Es[2][..., (-h + h // 2) * sf:, :w // 2 * sf]
+    E[..., h // 2 * sf:h * sf, w // 2 * sf:w * sf] = Es[3][..., (-h + h // 2) * sf:, (-w + w // 2) * sf:]
+    return E
+
+
+def test_mode(model, L, mode=0, refield=32, min_size=256, sf=1, modulo=1):
+    """utils/utils_model.py:12-37, the modes the solvers use: 0 (plain) and 2 (split)."""
+    if mode == 0:
+        return model(L)
+    if mode == 2:
+        return test_split_fn(model, L, refield, min_size, sf, modulo)
+    raise NotImplementedError('test_mode %d is not reached by the PnP solvers' % mode)
+
+
+class Denoiser:
+    """`denoising_step2` (S6:18-67) == `denoising_step1` (S3:19-68) bound to one model: maps a
+    [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
+
+    def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
+                 cnn_batch=64):
+        self.name, self.fam = model_name, family(model_name)
+        self.model = model
+        self.noise_level_model = noise_level_model
+        self.sigmas = sigmas              # torch tensor [iter_num] (drunet / ircnn)
+        self.x8 = x8
+        self.bank = bank                  # ircnn: {str(idx): state_dict}
+        self.former_idx = 0
+        self.cnn_batch = cnn_batch
+        self.noise_map = None
+        if self.fam == 'fdncnn':
+            if noises is None:
+                raise ValueError('fdncnn needs `noises` for its noise-level map (S6:26-29)')
+            nm = np.absolute(np.asarray(noises)).astype(np.float32) / np.float32(255.)
+            self.noise_map = torch.from_numpy(nm)[None, None]          # [1,1,H,W]
+
+    def to(self, device):
+        self.model = self.model.to(device)
+        if self.sigmas is not None:
+            self.sigmas = self.sigmas.to(device)
+        if self.noise_map is not None:
+            self.noise_map = self.noise_map.to(device)
+        return self
+
+    def select_bank(self, i):
+        """IRCNN's 25-model bank: index from sigma_i, reload on change (S6:289-298)."""
+        if self.fam != 'ircnn' or self.bank is None:
+            return
+        current_idx = int(np.ceil(float(self.sigmas[i]) * 255. / 2.) - 1)
+        if current_idx != self.former_idx:
+            self.model.load_state_dict(self.bank[str(current_idx)], strict=True)
+            self.model.eval()
+        self.former_idx = current_idx
+
+    def _one(self, x, i):
+        fam = self.fam
+        if fam == 'dncnn':
+            return self.model(x)
+        if fam == 'fdncnn':
+            return self.model(torch.cat((x, self.noise_map.expand(x.shape[0], -1, -1, -1)), dim=1))
+        if fam == 'drunet':
+            if self.x8:
+                x = augment_img_tensor4(x, i % 8)
+            s = self.sigmas[i].float().reshape(1, 1, 1, 1).expand(x.shape[0], 1, x.shape[2], x.shape[3])
+            x = test_mode(self.model, torch.cat((x, s), dim=1), mode=2, refield=32, min_size=256, modulo=16)
+            if self.x8:
+                x = augment_img_tensor4(x, 8 - i % 8 if i % 8 in (3, 5) else i % 8)
+            return x
+        if fam == 'ircnn':
+            if self.x8:
+                x = augment_img_tensor4(x, i % 8)
+            x = self.model(x)
+            if self.x8:
+                x = augment_img_tensor4(x, 8 - i % 8 if i % 8 in (3, 5) else i % 8)
+            return x
+        sigma = torch.full((1, 1, 1, 1), self.noise_level_model / 255., dtype=x.dtype, device=x.device)
+        return self.model(x, sigma)
+
+    @torch.no_grad()
+    def __call__(self, x, i, out=None):
+        B = x.shape[0]
+        if out is None:
+            out = torch.empty_like(x)
+        for b0 in range(0, B, self.cnn_batch):
+            out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)
+        return out

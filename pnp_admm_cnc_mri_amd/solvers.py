@@ -110,8 +110,9 @@ class _Job:
         eng.init_state()                                                                  # S4:103-109
         return eng
 
-    def finish(self, eng, x, x_dev=None, extra=''):
-        """S4:138-172: out list, optional PNGs, PSNR/SSIM/RE log lines, averages."""
+    def finish(self, eng, x, x_dev=None, extra='', x_metric=None):
+        """S4:138-172: out list, optional PNGs, PSNR/SSIM/RE log lines, averages.
+        x_metric: the image the host-side SSIM is taken on (PnP: the uint8-quantised x, S6:314)."""
         A = np.zeros((self.H, self.W), dtype='uint8')
         out = [A] * max(22, self.B)
         psnr1 = [0] * max(22, self.B)
@@ -122,7 +123,8 @@ class _Job:
             psnr, re = eng.metrics(x_dev, self.gt_u8)                                     # device reductions
             info['psnr'], info['re'] = list(map(float, psnr)), list(map(float, re))
             if self.ssim:
-                info['ssim'] = [float(_metrics.calculate_ssim(x[n].astype(np.float64) * 255, self.gt_u8[n]))
+                xm = x if x_metric is None else x_metric
+                info['ssim'] = [float(_metrics.calculate_ssim(xm[n].astype(np.float64) * 255, self.gt_u8[n]))
                                 for n in range(self.B)]
             for n in range(self.B):
                 psnr1[n] = info['psnr'][n]

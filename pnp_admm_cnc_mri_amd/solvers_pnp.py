@@ -1,0 +1,188 @@
+"""Plug-and-play solver entry points with the reference's signatures:
+
+    PNP_ADMM_L1_D(model_name, mask, noises, **opts)                 -> out            (S3:77-337)
+    PNP_ADMM_CNC_D(model_name, mask, noises, **opts)                -> (out, psnr1)   (S6:79-351)
+    PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, **o) -> (out, psnr1)   (S6:372-567)
+
+(S3 = "【3】PNP_ADMM_L1_D  .py", S6 = "【6】PNP_ADMM_CNC_D .py".)  The x-update runs in the HIP
+engine (pnp_dc_step on torch's current stream), the denoiser is a PyTorch-ROCm module, the
+pointwise glue (S6:301, 305-308) runs in HIP kernels on the tensors' device pointers.  State never
+leaves the device; what the reference's host<->device marshalling does to the numbers is kept:
+float32 state, |z| and |w| (no-ops once clamped), clamp(0,1) of x, z and w after every iteration.
+
+Extra keyword arguments (all optional): images=, y=, mask_id=, testsets=, testset_name=, results=,
+save_E=, device=, return_info=  as in solvers.py, plus
+    model_zoo='model_zoo'   directory of KAIR .pth files (S6:107-109)
+    model= / model2=        an nn.Module (or state_dict) instead of a file
+    cnn_batch=64            slices per CNN forward (activation memory)
+"""
+import os
+
+import numpy as np
+
+from . import denoisers as D
+from . import utils_pnp as pnp
+from .solvers import _Job
+
+PRESETS = {
+    # PNP_ADMM_CNC_D(alpha, iter, lambda1, reo, b), S6:569-577
+    'PNP_ADMM_CNC_D': {
+        'fdncnn': dict(alpha=0.9, iter_num=50, lambda1=0.2, reo=0.45, b=0.3),
+        'ffdnet': dict(alpha=0.9, iter_num=50, lambda1=1.35, reo=0.45, b=0.3),
+        'ircnn': dict(alpha=0.5, iter_num=50, lambda1=1.3, reo=0.45, b=2),
+        'drunet': dict(alpha=1, iter_num=50, lambda1=0.8, reo=0.8, b=0.45),
+    },
+    'PNP_ADMM_CNC_DnCNN': dict(alpha=1.2, iter_num=50, lambda1=4, reo=0.45, b=0.3),     # S6:571
+    # PNP_ADMM_L1_D(iter, reo), S3:339-347
+    'PNP_ADMM_L1_D': {
+        'fdncnn': dict(iter_num=50, reo=0.25), 'dncnn': dict(iter_num=50, reo=0.15),
+        'ffdnet': dict(iter_num=50, reo=0.25), 'ircnn': dict(iter_num=50, reo=0.145),
+        'drunet': dict(iter_num=50, reo=0.26),
+    },
+}
+
+
+def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, device):
+    """The model-zoo switch of S6:129-217: build by name, load weights, eval, no grad, to device."""
+    import torch
+    net, nlm, scheduled = D.build(model_name)
+    bank = None
+    if model is None:
+        path = os.path.join(model_zoo, model_name + '.pth')
+        if not os.path.exists(path):
+            raise FileNotFoundError('%s not found (the reference ships no weights, model_zoo/README.md); pass model= '
+                                    'or put KAIR weights there' % path)
+        model = torch.load(path, map_location='cpu')
+    if isinstance(model, torch.nn.Module):
+        net = model
+    elif D.family(model_name) == 'ircnn' and all(k.isdigit() for k in model.keys()):
+        bank = model                                   # dict of 25 state_dicts keyed by str(index), S6:196
+        net.load_state_dict(bank['0'] if '0' in bank else next(iter(bank.values())), strict=True)
+    else:
+        net.load_state_dict(model, strict=True)
+    net.eval()
+    for _, v in net.named_parameters():
+        v.requires_grad = False
+    sigmas = None
+    if scheduled:                                      # S6:172-174, 191-193
+        _, s = pnp.get_rho_sigma(sigma=max(0.255 / 255., nlm), iter_num=iter_num, modelSigma1=49,
+                                 modelSigma2=nlm * 255., w=1.0)
+        sigmas = torch.tensor(s)
+    return D.Denoiser(model_name, net, nlm, sigmas=sigmas, noises=noises, x8=x8, bank=bank, cnn_batch=cnn_batch).to(device)
+
+
+def _device_state(torch, eng, B, H, W, dev):
+    z0, w0 = eng.get_state()                           # z0 = |ifft2(y)|, w0 = 0 (S6:253-256)
+    z = torch.from_numpy(z0).to(dev).reshape(B, 1, H, W).contiguous()
+    w = torch.from_numpy(w0).to(dev).reshape(B, 1, H, W).contiguous()
+    x = torch.empty_like(z)
+    return x, z, w
+
+
+def _finish_pnp(torch, job, eng, x, extra):
+    """S6:314-351: img_E = uint8(round(x*255)); metrics on the quantised image."""
+    xq = torch.round(x * 255.0) / 255.0
+    out, psnr1, info = job.finish(eng, x.reshape(job.B, job.H, job.W).cpu().numpy(), x_dev=xq.contiguous(),
+                                  extra=extra, x_metric=xq.reshape(job.B, job.H, job.W).cpu().numpy())
+    return out, psnr1, info
+
+
+def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
+                   testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
+                   model_zoo='model_zoo', model=None, cnn_batch=64, **PNP_ADMM_CNC_D_opts):
+    """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
+    import torch
+    alpha = PNP_ADMM_CNC_D_opts.get('alpha', 0.4)          # S6:85-89
+    iter_num = PNP_ADMM_CNC_D_opts.get('iter_num', 46)
+    lambda1 = PNP_ADMM_CNC_D_opts.get('lambda1', 2.75)
+    reo = PNP_ADMM_CNC_D_opts.get('reo', 1)
+    b = PNP_ADMM_CNC_D_opts.get('b', 1)
+    dev = torch.device('cuda', device)
+    job = _Job(mask, noises, model_name, 'PNP_ADMM_CNC_D', images, y, mask_id, testsets, testset_name, results,
+               save_E, device)
+    den = _load_model(model_name, model, model_zoo, iter_num, noises, False, cnn_batch, dev)   # x8 = False, S6:93
+    with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        B, H, W = job.B, job.H, job.W
+        x, z, w = _device_state(torch, eng, B, H, W, dev)
+        s = torch.empty_like(z)
+        t = torch.empty_like(z)
+        z_new = torch.empty_like(z)
+        for i in range(iter_num):                                             # S6:262
+            eng.dc_step(z, w, x, reo)                                         # S6:266-271
+            den.select_bank(i)                                                # S6:289-298
+            den(z, i, out=s)                                                  # S6:300
+            eng.cnc_combine(z, x, w, s, t, alpha, lambda1, reo, b)            # S6:301
+            den(t, i, out=z_new)                                              # S6:302
+            eng.dual_clamp(x, z_new, w)                                       # S6:305-308
+            z, z_new = z_new, z
+        torch.cuda.current_stream(dev).synchronize()
+        out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha))
+    return (out, psnr1, info) if return_info else (out, psnr1)
+
+
+def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
+                       testsets='testsets', testset_name='Set1', results='results', save_E=None, device=0,
+                       return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
+                       faithful_model2_path=True, **opts):
+    """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
+    `faithful_model2_path`: the reference loads model_path1 into BOTH nets (S6:435) although it logs
+    path 2; True reproduces that, False loads model_name2's own weights."""
+    import torch
+    alpha = opts.get('alpha', 0.4)
+    iter_num = opts.get('iter_num', 46)
+    lambda1 = opts.get('lambda1', 2.75)
+    reo = opts.get('reo', 1)
+    b = opts.get('b', 1)
+    dev = torch.device('cuda', device)
+    job = _Job(mask, noises, model_name1 + '_' + model_name2, 'PNP_ADMM_CNC_DnCNN', images, y, mask_id, testsets,
+               testset_name, results, save_E, device)
+    den1 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev)
+    if faithful_model2_path and model2 is None:
+        den2 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev)
+    else:
+        den2 = _load_model(model_name2, model2, model_zoo, iter_num, noises, False, cnn_batch, dev)
+    with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        B, H, W = job.B, job.H, job.W
+        x, z, w = _device_state(torch, eng, B, H, W, dev)
+        s, t, z_new = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        for i in range(iter_num):                                             # S6:491
+            eng.dc_step(z, w, x, reo)                                         # S6:495-500
+            den1(z, i, out=s)                                                 # S6:517
+            eng.cnc_combine(z, x, w, s, t, alpha, lambda1, reo, b)            # S6:518
+            den2(t, i, out=z_new)                                             # S6:519
+            eng.dual_clamp(x, z_new, w)                                       # S6:522-525
+            z, z_new = z_new, z
+        torch.cuda.current_stream(dev).synchronize()
+        out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha))
+    return (out, psnr1, info) if return_info else (out, psnr1)
+
+
+def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
+                  testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
+                  model_zoo='model_zoo', model=None, cnn_batch=64, **PNP_ADMM_L1_D_opts):
+    """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
+    import torch
+    iter_num = PNP_ADMM_L1_D_opts.get('iter_num', 20)      # S3:83-84
+    reo = PNP_ADMM_L1_D_opts.get('reo', 0.04)
+    dev = torch.device('cuda', device)
+    fam = D.family(model_name)
+    x8 = fam in ('drunet', 'ffdnet')                       # x8 = True (S3:87) survives only there (S3:130,142,181)
+    job = _Job(mask, noises, model_name, 'PNP_ADMM_L1_D', images, y, mask_id, testsets, testset_name, results,
+               save_E, device)
+    den = _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, dev)
+    with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        B, H, W = job.B, job.H, job.W
+        x, z, w = _device_state(torch, eng, B, H, W, dev)
+        t = torch.empty_like(z)
+        for i in range(iter_num):                                             # S3:255
+            eng.dc_step(z, w, x, reo)                                         # S3:259-264
+            den.select_bank(i)
+            eng.add(x, w, t)                                                  # x + w
+            den(t, i, out=z)                                                  # S3:290
+            eng.dual_clamp(x, z, w)                                           # S3:293-296
+        torch.cuda.current_stream(dev).synchronize()
+        out, _, info = _finish_pnp(torch, job, eng, x, '')
+    return (out, info) if return_info else out
