@@ -128,13 +128,14 @@ def main():
     eng.x(out=x_dev)
     eng.sync()
     if dist is not None:
-        bufs = [torch.empty_like(x_dev) for _ in range(world)] if rank == 0 else None
+        from pnp_admm_cnc_mri_amd import sharding
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        dist.gather(x_dev, bufs, dst=0)
+        x_all = sharding.gather_slices(x_dev, world * B, dst=0)       # one direct RCCL gather over xGMI
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        assert (x_all is not None) == (rank == 0)
         t = torch.tensor([wall_ms, ev_ms, gather_ms], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_ms, ev_ms, gather_ms = (float(v) for v in t.cpu())

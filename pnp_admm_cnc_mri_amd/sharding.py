@@ -1,0 +1,60 @@
+"""Slice sharding across the GPUs of one node.
+
+Every slice has its own (y, mask, z, w): there is no cross-slice term anywhere in the
+reference (its outer `for` over images, S4:83, carries no state), so N processes -- one per
+GPU, `torch.distributed` over RCCL -- each run the whole ADMM loop on a contiguous block of
+slices with ZERO communication, and one gather of the float32 reconstructions ends the job.
+
+On the MI355X xGMI mesh every peer has its own link to the root, so the gather is issued as
+one direct `dist.gather` (peers -> root in parallel, 7 links), not a ring.
+Works with backend "nccl" (= RCCL, device tensors) and "gloo" (CPU tensors; used by the
+world_size-2 tests).
+"""
+import numpy as np
+
+
+def shard_range(B, world, rank):
+    """Contiguous block [lo, hi) of rank `rank`: sizes differ by at most one, earlier ranks larger."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError('bad world/rank %d/%d' % (world, rank))
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(B, world):
+    return [shard_range(B, world, r)[1] - shard_range(B, world, r)[0] for r in range(world)]
+
+
+def gather_slices(x_local, B_total, dst=0, group=None):
+    """x_local: torch tensor [b_r, H, W] of this rank (device tensor for nccl, CPU for gloo).
+    Returns the [B_total, H, W] tensor on `dst` (None elsewhere).  Uneven shards are padded to
+    the largest shard for the collective and trimmed on the root."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = shard_sizes(B_total, world)
+    if x_local.shape[0] != sizes[rank]:
+        raise ValueError('rank %d holds %d slices, expected %d' % (rank, x_local.shape[0], sizes[rank]))
+    bmax = max(sizes)
+    send = x_local.contiguous()
+    if send.shape[0] != bmax:
+        pad = torch.zeros((bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        pad[:send.shape[0]] = send
+        send = pad
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
+
+
+def run_sharded(solve_shard, B_total, group=None, dst=0):
+    """solve_shard(lo, hi) -> torch tensor [hi-lo, H, W]; runs it on this rank's block and gathers.
+    With no process group initialised it is a plain single-process call."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return solve_shard(0, B_total)
+    lo, hi = shard_range(B_total, dist.get_world_size(group), dist.get_rank(group))
+    return gather_slices(solve_shard(lo, hi), B_total, dst=dst, group=group)
