@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, 'include', 'pnp_mri.h')
 def _declared():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(pnp_[a-z0-9_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(pnp_[A-Za-z0-9_]+)\s*\(', src)))
 
 
 def test_header_and_binding_agree():
