@@ -8,10 +8,12 @@
 // mirror 256-k2 together.
 //
 //   T  : [pair][r][k2]           c32     row-FFT'd field, 512 KiB per pair (in place both ways)
-//   Yh : [pair][k2:129][j:16][t:16] float4 {Yh_a.re, Yh_a.im, Yh_b.re, Yh_b.im} at k1 = t + 16 j
-//   Mh : [pair][k2:129][t:16]    u64     nibble j = (2 Mh_a) | (2 Mh_b) << 2 at k1 = t + 16 j
-// (j, t) is exactly the (register, lane) a value has after the cooperative FFT of fft16.h, so a
-// lane's 16 blend operands are 16 coalesced 16-byte loads and one 8-byte load.
+//   Yh : [pair][tile m:9][wave:4][j:16][kl:16][tq:4] float4 {Yh_a.re, Yh_a.im, Yh_b.re, Yh_b.im}
+//        for k2 = 16 m + kl (m = 8: k2 = 128 only), k1 = t + 16 j, t = 4 wave + tq
+//   Mh : [pair][tile m:9][wave:4][kl:16][tq:4] u64, nibble j = (2 Mh_a) | (2 Mh_b) << 2
+// i.e. exactly thread order of the column kernel (lane = kl + 16 tq inside wave `wave` of tile m):
+// every wave-level operand load is one contiguous, fully coalesced 1-KiB (Yh) / 512-B (Mh) access,
+// and (j, t) is the (register, lane) the value meets after the cooperative FFT of fft16.h.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -22,8 +24,18 @@ namespace pnp {
 constexpr int F_N = 256;
 constexpr int F_HALF = 129;                  // k2 = 0..128
 
-PNP_HD size_t yh_index(int pair, int k2, int j, int t) { return (((size_t)pair * F_HALF + k2) * 16 + j) * 16 + t; }
-PNP_HD size_t mh_index(int pair, int k2, int t) { return ((size_t)pair * F_HALF + k2) * 16 + t; }
+constexpr int F_TILES = 9;                   // 8 tiles of 16 column pairs + the tile of column 128
+constexpr size_t YH_PAIR = (size_t)F_TILES * 4 * 16 * 16 * 4;     // float4 per slice pair
+constexpr size_t MH_PAIR = (size_t)F_TILES * 4 * 16 * 4;          // u64 per slice pair
+
+PNP_HD size_t yh_index(int pair, int k2, int j, int t) {
+    const int m = k2 >> 4, kl = k2 & 15, wv = t >> 2, tq = t & 3;
+    return (size_t)pair * YH_PAIR + ((((size_t)(m * 4 + wv) * 16 + j) * 16 + kl) * 4 + tq);
+}
+PNP_HD size_t mh_index(int pair, int k2, int t) {
+    const int m = k2 >> 4, kl = k2 & 15, wv = t >> 2, tq = t & 3;
+    return (size_t)pair * MH_PAIR + (((size_t)(m * 4 + wv) * 16 + kl) * 4 + tq);
+}
 
 // Hermitian-symmetrised measurement and mask code of one slice at (k1, k2).
 // y, mask: the slice's [256][256] arrays.

@@ -89,14 +89,21 @@ struct FRowArgs {
 //   [0]=col 0, [1]=col 128, [2q]=col q, [2q+1]=col 256-q   (q = 1..127)
 __device__ __forceinline__ int phi(int k) { return k < 128 ? 2 * k : (k == 128 ? 1 : 513 - 2 * k); }
 
+template <bool INV>
+__device__ __forceinline__ void fft256_head_lds(c32 (&a)[16], const c32* twl, int t) {
+    dft16<INV>(a);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twl[t * k]);
+}
+
 constexpr int RP = 272;    // staging pitch (c32) of a row in LDS: 272 % 32 == 16 -> two rows per
                            // 32-lane ds_read_b64 group land on disjoint bank halves
 constexpr int XP = 289;    // exchange region per 16-lane group, runs of 17 (289 % 32 == 1)
 
 // 16x16 transpose between the lanes of a group; region = this group's XP-sized LDS area
 template <bool INV>
-__device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32 (&tw)[16], c32* region, int t) {
-    fft256_head<INV>(a, tw);
+__device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32* twl, c32* region, int t) {
+    fft256_head_lds<INV>(a, twl, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) region[k * 17 + t] = a[k];
     __syncthreads();
@@ -109,14 +116,13 @@ __device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32 (&tw)[16], c3
 // PROX: 0 none, 1 L1, 2 CNC
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
-    __shared__ __attribute__((aligned(16))) c32 lds[16 * XP];
+    __shared__ __attribute__((aligned(16))) c32 lds[16 * XP + 256];
     const int tid = threadIdx.x, g = tid >> 4, t = tid & 15;
+    c32* twl = lds + 16 * XP;                  // W256 table (read where used, not held in VGPRs)
+    twl[tid] = g_twf[tid];
     const int pair = blockIdx.x >> 4, r0 = (blockIdx.x & 15) * 16;
     const int sa = 2 * pair, sb = sa + 1;
     const bool has_b = sb < p.B;
-    c32 tw[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) tw[k] = g_twf[t * k];
     c32 a[16];
     c32* Tt = p.T + (size_t)pair * 65536 + (size_t)r0 * 256;     // this block's 16 rows, contiguous
 
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = lds[g * RP + phi(t + 16 * j)];
         __syncthreads();
-        row_fft256<true>(a, tw, lds + g * XP, t);
+        row_fft256<true>(a, twl, lds + g * XP, t);
 #pragma unroll
         for (int j = 0; j < 16; ++j) lds[g * RP + t + 16 * j] = a[j];
         __syncthreads();
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = lds[g * RP + t + 16 * j];
         __syncthreads();
-        row_fft256<false>(a, tw, lds + g * XP, t);
+        row_fft256<false>(a, twl, lds + g * XP, t);
 #pragma unroll
         for (int j = 0; j < 16; ++j) lds[g * RP + phi(t + 16 * j)] = a[j];
         __syncthreads();
@@ -228,7 +234,7 @@ __device__ __forceinline__ void col_exchange(c32 (&a)[16], c32* region, int t) {
 }
 
 __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
-    __shared__ c32 lds[16 * CP];
+    __shared__ c32 lds[16 * CP + 256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kl = lane & 15, t = 4 * wv + (lane >> 4);
     const int pair = blockIdx.x / 9, m = blockIdx.x % 9;
@@ -238,9 +244,10 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
     const int k2 = self ? (kl == 0 ? 0 : 128) : 16 * m + kl;
     const bool valid = self ? (kl < 2) : (k2 >= 1);
     c32* Tp = p.T + (size_t)pair * 65536;
-    c32 tw[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) tw[k] = g_twf[t * k];
+    // W256 table in LDS: twiddles are fetched where they are used (ds_read_b64, 4 distinct
+    // addresses per wave) instead of occupying 32 VGPRs for the whole kernel
+    c32* twl = lds + 16 * CP;
+    twl[tid] = g_twf[tid];
     c32 P[16], Q[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -259,10 +266,11 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
         }
     }
     c32* region = lds + kl * CP;
-    fft256_head<false>(P, tw);
+    __syncthreads();                             // twiddle table visible
+    fft256_head_lds<false>(P, twl, t);
     col_exchange<false>(P, region, t);
     fft256_tail<false>(P);                       // P[j] = C[k1 = t + 16 j, k2]
-    fft256_head<true>(Q, tw);
+    fft256_head_lds<true>(Q, twl, t);
     col_exchange<true>(Q, region, t);
     fft256_tail<true>(Q);                        // Q[j] = C[-k1, -k2]
     if (valid) {
@@ -275,10 +283,10 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
             blend_pair(P[j], Q[j], mk(yh.x, yh.y), mk(yh.z, yh.w), nibv & 3, nibv >> 2, p.c, ch);
         }
     }
-    fft256_head<true>(P, tw);
+    fft256_head_lds<true>(P, twl, t);
     col_exchange<true>(P, region, t);
     fft256_tail<true>(P);                        // column k2 of the blended field
-    fft256_head<false>(Q, tw);
+    fft256_head_lds<false>(Q, twl, t);
     col_exchange<false>(Q, region, t);
     fft256_tail<false>(Q);                       // column 256 - k2
     if (valid) {
@@ -299,8 +307,8 @@ Fused256* fused256_create(int Bmax, hipError_t* err) {
     f->Bmax = Bmax;
     f->np = (Bmax + 1) / 2;
     hipError_t e = hipMalloc((void**)&f->T, (size_t)f->np * 65536 * sizeof(c32));
-    if (e == hipSuccess) e = hipMalloc((void**)&f->Yh, (size_t)f->np * F_HALF * 256 * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)f->np * F_HALF * 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Yh, (size_t)f->np * YH_PAIR * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)f->np * MH_PAIR * sizeof(unsigned long long));
     if (e == hipSuccess) {
         static thread_local c32 h[256];
         for (int m = 0; m < 256; ++m) {
@@ -344,8 +352,8 @@ static hipError_t launch_frows(hipStream_t s, int np, const FRowArgs& a) {
 static hipError_t launch_fcols(Fused256* f, hipStream_t s, int pair0, int np, float c) {
     FColArgs a;
     a.T = f->T + (size_t)pair0 * 65536;
-    a.Yh = f->Yh + (size_t)pair0 * F_HALF * 256;
-    a.Mh = f->Mh + (size_t)pair0 * F_HALF * 16;
+    a.Yh = f->Yh + (size_t)pair0 * YH_PAIR;
+    a.Mh = f->Mh + (size_t)pair0 * MH_PAIR;
     a.c = c;
     hipLaunchKernelGGL(k_fcols, dim3(np * 9), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -55,8 +55,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     // ---- prepare: Hermitian tables for the pair -------------------------------------------
-    std::vector<c32> Yha(129 * 256), Yhb(129 * 256);
-    std::vector<uint64_t> Mh(129 * 16, 0);
+    std::vector<c32> Yha(YH_PAIR), Yhb(YH_PAIR);
+    std::vector<uint64_t> Mh(MH_PAIR, 0);
     for (int k2 = 0; k2 <= 128; ++k2)
         for (int j = 0; j < 16; ++j)
             for (int t = 0; t < 16; ++t) {
