@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   2
+#define PNP_ABI_VERSION   3
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -124,6 +124,22 @@ int pnp_Df(pnp_ctx* ctx, const float* x_dev, float* out_dev);
  * x_dev = NULL means the ctx-owned x of the last pnp_admm_*_run. */
 int pnp_metrics(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_device,
                 double* psnr_host, double* re_host);
+
+/* ---- fp64 validation context ---------------------------------------------------------------
+ * The same loops (pnp_init_state, pnp_admm_l1_run, pnp_admm_cnc_run) with every buffer and every
+ * arithmetic step in double / complex128 on the generic kernels: the reference itself runs in
+ * float64 (S4:109 `w = np.zeros(..., dtype=np.float64)`), and its committed CNC presets amplify
+ * fp32 round-off ~1.08x per iteration, so this is the mode in which 100-iteration CNC runs meet
+ * 1e-5 end to end.  Not a throughput path; the step-wise / operator entry points are float-only
+ * and return PNP_E_STATE on such a context. */
+int pnp_ctx_create_f64(int device, int H, int W, int Bmax, pnp_ctx** out);
+/* y: [B][H][W] complex128 (interleaved doubles); masks as pnp_upload_problem. */
+int pnp_upload_problem_f64(pnp_ctx* ctx, const double* y, const uint8_t* mask_bank,
+                           const int32_t* mask_id, int B, int K, int on_device);
+int pnp_set_state_f64(pnp_ctx* ctx, const double* z, const double* w, int on_device);
+int pnp_get_state_f64(pnp_ctx* ctx, double* z, double* w, int on_device);
+int pnp_download_x_f64(pnp_ctx* ctx, double* x, int on_device);
+int pnp_is_f64(pnp_ctx* ctx);
 
 /* ---- timing on the ctx stream (HIP events) ------------------------------------------------ */
 int pnp_timer_start(pnp_ctx* ctx);

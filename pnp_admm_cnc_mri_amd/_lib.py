@@ -48,13 +48,19 @@ SIGNATURES = {
     'pnp_AH': (C.c_int, [ctx_p, _vp, _vp]),
     'pnp_Df': (C.c_int, [ctx_p, _vp, _vp]),
     'pnp_metrics': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p, c_double_p]),
+    'pnp_ctx_create_f64': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ctx_p)]),
+    'pnp_upload_problem_f64': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    'pnp_set_state_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
+    'pnp_get_state_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
+    'pnp_download_x_f64': (C.c_int, [ctx_p, _vp, C.c_int]),
+    'pnp_is_f64': (C.c_int, [ctx_p]),
     'pnp_timer_start': (C.c_int, [ctx_p]),
     'pnp_timer_stop': (C.c_int, [ctx_p, c_float_p]),
     'pnp_kernels_per_iteration': (C.c_int, [ctx_p]),
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -49,6 +49,11 @@ struct pnp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Fused256* fused = nullptr;
     bool fused_ready = false;         // tables prepared for the current problem
+    // fp64 validation context (pnp_ctx_create_f64): same loop, generic kernels, double buffers
+    bool f64 = false;
+    double2* yd = nullptr;
+    double2* workd = nullptr;
+    double *zd = nullptr, *wd = nullptr, *xd = nullptr;
 };
 
 static bool supported(int n) { return n == 256 || n == 512; }
@@ -85,7 +90,7 @@ int pnp_device_count(int* n) {
     return PNP_OK;
 }
 
-int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out) {
+static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, bool f64) {
     if (!out) return fail(PNP_E_ARG, "pnp_ctx_create: out is null");
     *out = nullptr;
     if (!supported(H) || !supported(W)) return fail(PNP_E_ARG, "pnp_ctx_create: H, W must be 256 or 512 (got %dx%d)", H, W);
@@ -93,15 +98,23 @@ int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out) {
     HIPCHK(hipSetDevice(device));
     pnp_ctx* c = new (std::nothrow) pnp_ctx();
     if (!c) return fail(PNP_E_NOMEM, "pnp_ctx_create: host allocation failed");
-    c->device = device; c->H = H; c->W = W; c->Bmax = Bmax; c->N = (size_t)H * W;
+    c->device = device; c->H = H; c->W = W; c->Bmax = Bmax; c->N = (size_t)H * W; c->f64 = f64;
     const size_t BN = (size_t)Bmax * c->N;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
-    alloc((void**)&c->y, BN * sizeof(float2));
-    alloc((void**)&c->work, BN * sizeof(float2));
-    alloc((void**)&c->z, BN * sizeof(float));
-    alloc((void**)&c->w, BN * sizeof(float));
-    alloc((void**)&c->x, BN * sizeof(float));
+    if (f64) {
+        alloc((void**)&c->yd, BN * sizeof(double2));
+        alloc((void**)&c->workd, BN * sizeof(double2));
+        alloc((void**)&c->zd, BN * sizeof(double));
+        alloc((void**)&c->wd, BN * sizeof(double));
+        alloc((void**)&c->xd, BN * sizeof(double));
+    } else {
+        alloc((void**)&c->y, BN * sizeof(float2));
+        alloc((void**)&c->work, BN * sizeof(float2));
+        alloc((void**)&c->z, BN * sizeof(float));
+        alloc((void**)&c->w, BN * sizeof(float));
+        alloc((void**)&c->x, BN * sizeof(float));
+    }
     alloc((void**)&c->mask_id, (size_t)Bmax * sizeof(int32_t));
     alloc((void**)&c->acc, (size_t)Bmax * 2 * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -111,7 +124,7 @@ int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out) {
         pnp_ctx_destroy(c);
         return fail(e == hipErrorOutOfMemory ? PNP_E_NOMEM : PNP_E_HIP, "pnp_ctx_create: %s", hipGetErrorString(e));
     }
-    if (H == 256 && W == 256) {
+    if (!f64 && H == 256 && W == 256) {
         hipError_t fe = hipSuccess;
         c->fused = fused256_create(Bmax, &fe);      // null when the fused path is unavailable
         if (!c->fused && fe != hipSuccess && fe != hipErrorNotSupported) {
@@ -123,11 +136,15 @@ int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out) {
     return PNP_OK;
 }
 
+int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out) { return ctx_create_any(device, H, W, Bmax, out, false); }
+int pnp_ctx_create_f64(int device, int H, int W, int Bmax, pnp_ctx** out) { return ctx_create_any(device, H, W, Bmax, out, true); }
+
 int pnp_ctx_destroy(pnp_ctx* c) {
     if (!c) return PNP_OK;
     (void)hipSetDevice(c->device);
     if (c->fused) fused256_destroy(c->fused);
-    void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage};
+    void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage,
+                    c->yd, c->workd, c->zd, c->wd, c->xd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -137,6 +154,8 @@ int pnp_ctx_destroy(pnp_ctx* c) {
 
 #define CTX(c) do { if (!(c)) return fail(PNP_E_ARG, "%s: ctx is null", __func__); HIPCHK(hipSetDevice((c)->device)); } while (0)
 #define NEED_PROBLEM(c) do { if ((c)->B <= 0) return fail(PNP_E_STATE, "%s: no problem uploaded", __func__); } while (0)
+#define F32_ONLY(c) do { if ((c)->f64) return fail(PNP_E_STATE, "%s: not available on an fp64 validation context", __func__); } while (0)
+#define F64_ONLY(c) do { if (!(c)->f64) return fail(PNP_E_STATE, "%s: needs a context made by pnp_ctx_create_f64", __func__); } while (0)
 
 int pnp_set_stream(pnp_ctx* c, void* s) { CTX(c); c->stream = (hipStream_t)s; return PNP_OK; }
 int pnp_sync(pnp_ctx* c) { CTX(c); HIPCHK(hipStreamSynchronize(c->stream)); return PNP_OK; }
@@ -184,7 +203,7 @@ static int prepare_fused(pnp_ctx* c) {
 }
 
 int pnp_upload_problem(pnp_ctx* c, const float* y, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
-    CTX(c);
+    CTX(c); F32_ONLY(c);
     if (!y) return fail(PNP_E_ARG, "pnp_upload_problem: y is null");
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
@@ -195,7 +214,7 @@ int pnp_upload_problem(pnp_ctx* c, const float* y, const uint8_t* mask_bank, con
 
 int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int noise_per_slice,
                            const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
-    CTX(c);
+    CTX(c); F32_ONLY(c);
     if (!img || !noise) return fail(PNP_E_ARG, "pnp_synthesize_problem: img/noise is null");
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
@@ -226,13 +245,24 @@ int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int
 }
 
 int pnp_download_y(pnp_ctx* c, float* y, int on_device) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!y) return fail(PNP_E_ARG, "pnp_download_y: null");
     return copy_out(c, y, c->y, (size_t)c->B * c->N * sizeof(float2), on_device);
 }
 
 int pnp_init_state(pnp_ctx* c) {
     CTX(c); NEED_PROBLEM(c);
+    if (c->f64) {
+        ColArgsT<double> ca{};
+        ca.in = c->yd; ca.out = c->workd; ca.B = c->B;
+        HIPCHK(launch_cols<double>(c->stream, c->H, c->W, false, MID_NONE, true, ca));
+        RowArgsT<double> ra{};
+        ra.cin = c->workd; ra.x_out = c->zd; ra.scale = 1.0 / (double)c->N; ra.nrows = c->B * c->H;
+        HIPCHK(launch_rows<double>(c->stream, c->W, IN_COMPLEX, true, EPI_ABS_COMPLEX, ra));
+        HIPCHK(hipMemsetAsync(c->wd, 0, (size_t)c->B * c->N * sizeof(double), c->stream));
+        c->have_x = false;
+        return PNP_OK;
+    }
     ColArgs ca{};
     ca.in = c->y; ca.out = c->work; ca.B = c->B;
     HIPCHK(launch_cols(c->stream, c->H, c->W, false, MID_NONE, true, ca));
@@ -245,7 +275,7 @@ int pnp_init_state(pnp_ctx* c) {
 }
 
 int pnp_set_state(pnp_ctx* c, const float* z, const float* w, int on_device) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(float);
     int rc;
     if (z) { rc = copy_in(c, c->z, z, bytes, on_device); if (rc) return rc; }
@@ -255,7 +285,7 @@ int pnp_set_state(pnp_ctx* c, const float* z, const float* w, int on_device) {
 }
 
 int pnp_get_state(pnp_ctx* c, float* z, float* w, int on_device) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(float);
     int rc;
     if (z) { rc = copy_out(c, z, c->z, bytes, on_device); if (rc) return rc; }
@@ -280,6 +310,25 @@ static int generic_iteration(pnp_ctx* c, const float* z_in, const float* w_in, R
     return PNP_OK;
 }
 
+static int run_loop_f64(pnp_ctx* c, int iters, bool cnc, const ProxParamsT<double>& pp, double reo) {
+    const double cdc = 1.0 / (1.0 + 1.0 / 2.0 / reo);
+    for (int i = 0; i < iters; ++i) {
+        RowArgsT<double> ra{};
+        ra.rin0 = c->zd; ra.rin1 = c->wd; ra.cout = c->workd; ra.scale = 1.0; ra.nrows = c->B * c->H;
+        HIPCHK(launch_rows<double>(c->stream, c->W, IN_REAL_DIFF, false, EPI_COMPLEX, ra));
+        ColArgsT<double> ca{};
+        ca.in = c->workd; ca.out = c->workd; ca.y = c->yd; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id;
+        ca.c = cdc; ca.B = c->B;
+        HIPCHK(launch_cols<double>(c->stream, c->H, c->W, true, MID_BLEND, true, ca));
+        RowArgsT<double> rb{};
+        rb.cin = c->workd; rb.x_out = (i == iters - 1) ? c->xd : nullptr; rb.z = c->zd; rb.w = c->wd;
+        rb.scale = 1.0 / (double)c->N; rb.prox = pp; rb.nrows = c->B * c->H;
+        HIPCHK(launch_rows<double>(c->stream, c->W, IN_COMPLEX, true, cnc ? EPI_CNC : EPI_L1, rb));
+    }
+    c->have_x = true;
+    return PNP_OK;
+}
+
 static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, double reo) {
     if (iters < 0) return fail(PNP_E_ARG, "iters must be >= 0");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "reo must be > 0");
@@ -300,24 +349,35 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, doubl
 
 int pnp_admm_l1_run(pnp_ctx* c, int iters, double lambda1, double reo) {
     CTX(c); NEED_PROBLEM(c);
+    if (c->f64) {
+        if (iters < 0 || !(reo > 0.0)) return fail(PNP_E_ARG, "pnp_admm_l1_run: iters >= 0 and reo > 0 required");
+        ProxParamsT<double> p{}; p.thr = reo * lambda1;
+        return run_loop_f64(c, iters, false, p, reo);
+    }
     return run_loop(c, iters, false, make_prox_l1(lambda1, reo), reo);
 }
 
 int pnp_admm_cnc_run(pnp_ctx* c, int iters, double alpha, double lambda1, double reo, double b) {
     CTX(c); NEED_PROBLEM(c);
     if (!(b > 0.0)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: b must be > 0");
+    if (c->f64) {
+        if (iters < 0 || !(reo > 0.0)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: iters >= 0 and reo > 0 required");
+        ProxParamsT<double> p{};
+        p.thr = alpha * reo * lambda1; p.c1 = 1.0 - alpha; p.c2 = alpha; p.c3 = alpha * reo * lambda1 * b; p.ib = 1.0 / b;
+        return run_loop_f64(c, iters, true, p, reo);
+    }
     return run_loop(c, iters, true, make_prox_cnc(alpha, lambda1, reo, b), reo);
 }
 
 int pnp_download_x(pnp_ctx* c, float* x, int on_device) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!x) return fail(PNP_E_ARG, "pnp_download_x: null");
     if (!c->have_x) return fail(PNP_E_STATE, "pnp_download_x: no iteration has been run since the state was set");
     return copy_out(c, x, c->x, (size_t)c->B * c->N * sizeof(float), on_device);
 }
 
 int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
     if (use_fused(c)) {
@@ -328,7 +388,7 @@ int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo
 }
 
 int pnp_prox_l1_dual(pnp_ctx* c, const float* x, float* z, float* w, double thr) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_prox_l1_dual: null pointer");
     ProxParams p{}; p.thr = (float)thr;
     HIPCHK(launch_prox(c->stream, false, x, z, w, p, (size_t)c->B * c->N));
@@ -336,7 +396,7 @@ int pnp_prox_l1_dual(pnp_ctx* c, const float* x, float* z, float* w, double thr)
 }
 
 int pnp_prox_cnc_dual(pnp_ctx* c, const float* x, float* z, float* w, double alpha, double lambda1, double reo, double b) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: null pointer");
     if (!(b > 0.0)) return fail(PNP_E_ARG, "pnp_prox_cnc_dual: b must be > 0");
     HIPCHK(launch_prox(c->stream, true, x, z, w, make_prox_cnc(alpha, lambda1, reo, b), (size_t)c->B * c->N));
@@ -345,7 +405,7 @@ int pnp_prox_cnc_dual(pnp_ctx* c, const float* x, float* z, float* w, double alp
 
 int pnp_cnc_combine(pnp_ctx* c, const float* z, const float* x, const float* w, const float* s, float* t,
                     double alpha, double lambda1, double reo, double b) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!z || !x || !w || !s || !t) return fail(PNP_E_ARG, "pnp_cnc_combine: null pointer");
     HIPCHK(launch_combine(c->stream, z, x, w, s, t, (float)(1.0 - alpha), (float)alpha,
                           (float)(alpha * reo * lambda1 * b), (size_t)c->B * c->N));
@@ -353,14 +413,14 @@ int pnp_cnc_combine(pnp_ctx* c, const float* z, const float* x, const float* w, 
 }
 
 int pnp_add(pnp_ctx* c, const float* a, const float* b, float* o) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!a || !b || !o) return fail(PNP_E_ARG, "pnp_add: null pointer");
     HIPCHK(launch_add(c->stream, a, b, o, (size_t)c->B * c->N));
     return PNP_OK;
 }
 
 int pnp_dual_clamp(pnp_ctx* c, float* x, float* z, float* w) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!x || !z || !w) return fail(PNP_E_ARG, "pnp_dual_clamp: null pointer");
     HIPCHK(launch_dual_clamp(c->stream, x, z, w, (size_t)c->B * c->N));
     return PNP_OK;
@@ -378,11 +438,11 @@ static int fft2_any(pnp_ctx* c, const float* in, float* out, int B, bool inv) {
     return PNP_OK;
 }
 
-int pnp_fft2_fwd(pnp_ctx* c, const float* in, float* out, int B) { CTX(c); return fft2_any(c, in, out, B, false); }
-int pnp_fft2_inv(pnp_ctx* c, const float* in, float* out, int B) { CTX(c); return fft2_any(c, in, out, B, true); }
+int pnp_fft2_fwd(pnp_ctx* c, const float* in, float* out, int B) { CTX(c); F32_ONLY(c); return fft2_any(c, in, out, B, false); }
+int pnp_fft2_inv(pnp_ctx* c, const float* in, float* out, int B) { CTX(c); F32_ONLY(c); return fft2_any(c, in, out, B, true); }
 
 int pnp_A(pnp_ctx* c, const float* x, float* k) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!x || !k) return fail(PNP_E_ARG, "pnp_A: null pointer");
     RowArgs ra{};
     ra.rin0 = x; ra.cout = (float2*)k; ra.scale = 1.0f; ra.nrows = c->B * c->H;
@@ -394,7 +454,7 @@ int pnp_A(pnp_ctx* c, const float* x, float* k) {
 }
 
 int pnp_AH(pnp_ctx* c, const float* k, float* out) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!k || !out) return fail(PNP_E_ARG, "pnp_AH: null pointer");
     ColArgs ca{};
     ca.in = (const float2*)k; ca.out = (float2*)out; ca.mask_bank = c->mask_bank; ca.mask_id = c->mask_id; ca.B = c->B;
@@ -406,7 +466,7 @@ int pnp_AH(pnp_ctx* c, const float* k, float* out) {
 }
 
 int pnp_Df(pnp_ctx* c, const float* x, float* out) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!x || !out) return fail(PNP_E_ARG, "pnp_Df: null pointer");
     RowArgs ra{};
     ra.rin0 = x; ra.cout = (float2*)out; ra.scale = 1.0f; ra.nrows = c->B * c->H;
@@ -421,7 +481,7 @@ int pnp_Df(pnp_ctx* c, const float* x, float* out) {
 }
 
 int pnp_metrics(pnp_ctx* c, const float* x, const uint8_t* gt, int gt_on_device, double* psnr, double* re) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     if (!gt || !psnr || !re) return fail(PNP_E_ARG, "pnp_metrics: null pointer");
     if (!x) {
         if (!c->have_x) return fail(PNP_E_STATE, "pnp_metrics: x_dev is null and the ctx holds no x yet");
@@ -445,6 +505,45 @@ int pnp_metrics(pnp_ctx* c, const float* x, const uint8_t* gt, int gt_on_device,
     }
     return PNP_OK;
 }
+
+/* ---- fp64 validation context: problem / state / result in double ------------------------- */
+int pnp_upload_problem_f64(pnp_ctx* c, const double* y, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
+    CTX(c); F64_ONLY(c);
+    if (!y) return fail(PNP_E_ARG, "pnp_upload_problem_f64: y is null");
+    int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
+    if (rc) { c->B = 0; return rc; }
+    rc = copy_in(c, c->yd, y, (size_t)B * c->N * sizeof(double2), on_device);
+    if (rc) { c->B = 0; return rc; }
+    return PNP_OK;
+}
+
+int pnp_set_state_f64(pnp_ctx* c, const double* z, const double* w, int on_device) {
+    CTX(c); F64_ONLY(c); NEED_PROBLEM(c);
+    const size_t bytes = (size_t)c->B * c->N * sizeof(double);
+    int rc;
+    if (z) { rc = copy_in(c, c->zd, z, bytes, on_device); if (rc) return rc; }
+    if (w) { rc = copy_in(c, c->wd, w, bytes, on_device); if (rc) return rc; }
+    c->have_x = false;
+    return PNP_OK;
+}
+
+int pnp_get_state_f64(pnp_ctx* c, double* z, double* w, int on_device) {
+    CTX(c); F64_ONLY(c); NEED_PROBLEM(c);
+    const size_t bytes = (size_t)c->B * c->N * sizeof(double);
+    int rc;
+    if (z) { rc = copy_out(c, z, c->zd, bytes, on_device); if (rc) return rc; }
+    if (w) { rc = copy_out(c, w, c->wd, bytes, on_device); if (rc) return rc; }
+    return PNP_OK;
+}
+
+int pnp_download_x_f64(pnp_ctx* c, double* x, int on_device) {
+    CTX(c); F64_ONLY(c); NEED_PROBLEM(c);
+    if (!x) return fail(PNP_E_ARG, "pnp_download_x_f64: null");
+    if (!c->have_x) return fail(PNP_E_STATE, "pnp_download_x_f64: no iteration has been run since the state was set");
+    return copy_out(c, x, c->xd, (size_t)c->B * c->N * sizeof(double), on_device);
+}
+
+int pnp_is_f64(pnp_ctx* c) { return (c && c->f64) ? 1 : 0; }
 
 int pnp_timer_start(pnp_ctx* c) { CTX(c); HIPCHK(hipEventRecord(c->ev0, c->stream)); return PNP_OK; }
 int pnp_timer_stop(pnp_ctx* c, float* ms) {

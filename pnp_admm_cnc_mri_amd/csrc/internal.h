@@ -5,46 +5,60 @@
 
 namespace pnp {
 
-// Scalars of the z/w update, pre-combined on the host in double and rounded once to float.
-struct ProxParams {
-    float thr;      // L1: reo*lambda1            CNC: alpha*reo*lambda1   (outer soft threshold)
-    float c1;       // CNC: 1-alpha
-    float c2;       // CNC: alpha
-    float c3;       // CNC: alpha*reo*lambda1*b
-    float ib;       // CNC: 1/b   (inner clip level: z - soft(z,1/b) == clip(z,-1/b,1/b))
+// complex / real types per precision: float2 for the production path, double2 for the fp64
+// validation context (pnp_ctx_create_f64)
+template <typename R> struct CxOf;
+template <> struct CxOf<float>  { using type = float2; };
+template <> struct CxOf<double> { using type = double2; };
+
+// Scalars of the z/w update, pre-combined on the host in double and rounded once to R.
+template <typename R>
+struct ProxParamsT {
+    R thr;      // L1: reo*lambda1            CNC: alpha*reo*lambda1   (outer soft threshold)
+    R c1;       // CNC: 1-alpha
+    R c2;       // CNC: alpha
+    R c3;       // CNC: alpha*reo*lambda1*b
+    R ib;       // CNC: 1/b   (inner clip level: z - soft(z,1/b) == clip(z,-1/b,1/b))
 };
+using ProxParams = ProxParamsT<float>;
 
 enum RowIn  { IN_COMPLEX = 0, IN_REAL = 1, IN_REAL_DIFF = 2 };
 enum RowEpi { EPI_COMPLEX = 0, EPI_ABS_REAL = 1, EPI_ABS_COMPLEX = 2, EPI_L1 = 3, EPI_CNC = 4 };
 enum ColMid { MID_NONE = 0, MID_BLEND = 1, MID_MASK = 2, MID_RESID = 3, MID_MASK_ADD = 4 };
 
-struct RowArgs {
-    const float2* cin;     // IN_COMPLEX
-    const float*  rin0;    // IN_REAL / IN_REAL_DIFF (minuend)
-    const float*  rin1;    // IN_REAL_DIFF (subtrahend)
-    float2*       cout;    // EPI_COMPLEX
-    float*        x_out;   // EPI_ABS_* (required) / EPI_L1, EPI_CNC (optional, may be null)
-    float*        z;       // EPI_L1 / EPI_CNC: read old, write new
-    float*        w;
-    float         scale;   // applied to the transform output
-    ProxParams    prox;
-    int           nrows;   // B*H
+template <typename R>
+struct RowArgsT {
+    using C = typename CxOf<R>::type;
+    const C* cin;      // IN_COMPLEX
+    const R* rin0;     // IN_REAL / IN_REAL_DIFF (minuend)
+    const R* rin1;     // IN_REAL_DIFF (subtrahend)
+    C*       cout;     // EPI_COMPLEX
+    R*       x_out;    // EPI_ABS_* (required) / EPI_L1, EPI_CNC (optional, may be null)
+    R*       z;        // EPI_L1 / EPI_CNC: read old, write new
+    R*       w;
+    R        scale;    // applied to the transform output
+    ProxParamsT<R> prox;
+    int      nrows;    // B*H
 };
+using RowArgs = RowArgsT<float>;
 
-struct ColArgs {
-    const float2*  in;
-    float2*        out;        // may alias in
-    const float2*  y;          // MID_BLEND / MID_RESID: measurements; MID_MASK_ADD: noise
+template <typename R>
+struct ColArgsT {
+    using C = typename CxOf<R>::type;
+    const C*       in;
+    C*             out;        // may alias in
+    const C*       y;          // MID_BLEND / MID_RESID: measurements; MID_MASK_ADD: noise
     const uint8_t* mask_bank;  // [K][H][W]
     const int32_t* mask_id;    // [B] or null
-    float          c;          // MID_BLEND: 1/(1+La2)
+    R              c;          // MID_BLEND: 1/(1+La2)
     int            y_per_slice;// MID_MASK_ADD: 0 = one [H][W] noise array for all slices
     int            B;
 };
+using ColArgs = ColArgsT<float>;
 
-// generic path (kernels_generic.hip); H, W in {256, 512}
-hipError_t launch_rows(hipStream_t s, int W, RowIn in, bool inv, RowEpi epi, const RowArgs& a);
-hipError_t launch_cols(hipStream_t s, int H, int W, bool pre_fwd, ColMid mid, bool post_inv, const ColArgs& a);
+// generic path (kernels_generic.hip); H, W in {256, 512}; R = float | double
+template <typename R> hipError_t launch_rows(hipStream_t s, int W, RowIn in, bool inv, RowEpi epi, const RowArgsT<R>& a);
+template <typename R> hipError_t launch_cols(hipStream_t s, int H, int W, bool pre_fwd, ColMid mid, bool post_inv, const ColArgsT<R>& a);
 hipError_t upload_twiddles();       // fills the __device__ tables of the current device
 
 // pointwise

@@ -18,35 +18,51 @@ namespace pnp {
 
 __device__ float2 g_tw256[256];
 __device__ float2 g_tw512[512];
+__device__ double2 g_tw256d[256];      // fp64 validation context
+__device__ double2 g_tw512d[512];
 
 hipError_t upload_twiddles() {
     static thread_local float2 h[512];
+    static thread_local double2 hd[512];
     for (int N : {256, 512}) {
         for (int m = 0; m < N; ++m) {
-            double a = -2.0 * M_PI * (double)m / (double)N;
-            h[m] = make_float2((float)cos(a), (float)sin(a));
+            const double a = -2.0 * M_PI * (double)m / (double)N;
+            hd[m] = make_double2(cos(a), sin(a));
+            h[m] = make_float2((float)hd[m].x, (float)hd[m].y);
         }
         hipError_t e = (N == 256) ? hipMemcpyToSymbol(HIP_SYMBOL(g_tw256), h, sizeof(float2) * 256)
                                   : hipMemcpyToSymbol(HIP_SYMBOL(g_tw512), h, sizeof(float2) * 512);
+        if (e != hipSuccess) return e;
+        e = (N == 256) ? hipMemcpyToSymbol(HIP_SYMBOL(g_tw256d), hd, sizeof(double2) * 256)
+                       : hipMemcpyToSymbol(HIP_SYMBOL(g_tw512d), hd, sizeof(double2) * 512);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+template <typename R> struct Tw;
+template <> struct Tw<float>  { __device__ static const float2*  get(int N) { return N == 256 ? g_tw256 : g_tw512; } };
+template <> struct Tw<double> { __device__ static const double2* get(int N) { return N == 256 ? g_tw256d : g_tw512d; } };
+
+__device__ __forceinline__ float2  mkc(float x, float y)   { return make_float2(x, y); }
+__device__ __forceinline__ double2 mkc(double x, double y) { return make_double2(x, y); }
+__device__ __forceinline__ float  fma_r(float a, float b, float c)    { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename C> __device__ __forceinline__ C cmul(C a, C b) {
+    return mkc(fma_r(a.x, b.x, -(a.y * b.y)), fma_r(a.x, b.y, a.y * b.x));
 }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {   // a * conj(b)
-    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+template <typename C> __device__ __forceinline__ C cmulc(C a, C b) {   // a * conj(b)
+    return mkc(fma_r(a.x, b.x, a.y * b.y), fma_r(a.y, b.x, -(a.x * b.y)));
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return mkc(a.x + b.x, a.y + b.y); }
+template <typename C> __device__ __forceinline__ C csub(C a, C b) { return mkc(a.x - b.x, a.y - b.y); }
 
 // Length-N transform of the contiguous LDS array `a` by T cooperating threads (t in [0,T)),
 // scratch `b`; all threads of the workgroup must call it (block barriers inside).
 // Returns the buffer holding the result (natural order).
-template <int N, int T, bool INV>
-__device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const float2* tw, int t) {
+template <int N, int T, bool INV, typename C>
+__device__ __forceinline__ C* fft_lds(C* a, C* b, const C* tw, int t) {
     static_assert(N == 256 || N == 512, "N");
     int Ns = 1;
 #pragma unroll
@@ -54,15 +70,15 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const float2* t
         for (int j = t; j < N / 4; j += T) {
             const int k = j & (Ns - 1);
             const int ti = k * (N / (Ns * 4));
-            float2 v0 = a[j], v1 = a[j + N / 4], v2 = a[j + N / 2], v3 = a[j + 3 * N / 4];
+            C v0 = a[j], v1 = a[j + N / 4], v2 = a[j + N / 2], v3 = a[j + 3 * N / 4];
             if (s > 0) {
-                const float2 w1 = tw[ti], w2 = tw[2 * ti], w3 = tw[3 * ti];
+                const C w1 = tw[ti], w2 = tw[2 * ti], w3 = tw[3 * ti];
                 if (INV) { v1 = cmulc(v1, w1); v2 = cmulc(v2, w2); v3 = cmulc(v3, w3); }
                 else     { v1 = cmul(v1, w1);  v2 = cmul(v2, w2);  v3 = cmul(v3, w3); }
             }
-            const float2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3);
-            const float2 d = csub(v1, v3);
-            const float2 t3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // (+/-) i * d
+            const C t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3);
+            const C d = csub(v1, v3);
+            const C t3 = INV ? mkc(-d.y, d.x) : mkc(d.y, -d.x);   // (+/-) i * d
             const int j0 = ((j - k) << 2) + k;
             b[j0] = cadd(t0, t2);
             b[j0 + Ns] = cadd(t1, t3);
@@ -70,79 +86,85 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const float2* t
             b[j0 + 3 * Ns] = csub(t1, t3);
         }
         __syncthreads();
-        float2* tmp = a; a = b; b = tmp;
+        C* tmp = a; a = b; b = tmp;
         Ns *= 4;
     }
     if (N == 512) {                                   // final radix-2 stage, Ns = 256
         for (int j = t; j < N / 2; j += T) {
             const int k = j & 255;
-            float2 v0 = a[j], v1 = a[j + N / 2];
+            C v0 = a[j], v1 = a[j + N / 2];
             v1 = INV ? cmulc(v1, tw[k]) : cmul(v1, tw[k]);
             const int j0 = ((j - k) << 1) + k;
             b[j0] = cadd(v0, v1);
             b[j0 + 256] = csub(v0, v1);
         }
         __syncthreads();
-        float2* tmp = a; a = b; b = tmp;
+        C* tmp = a; a = b; b = tmp;
     }
     return a;
 }
 
-__device__ __forceinline__ float soft(float a, float c) { return copysignf(fmaxf(fabsf(a) - c, 0.0f), a); }
-
-__device__ __forceinline__ void prox_l1(float x, float& z, float& w, const ProxParams& p) {
-    const float u = x + w;
+template <typename R> __device__ __forceinline__ R soft(R a, R c) {
+    const R m = fabs(a) - c;
+    const R r = m > R(0) ? m : R(0);
+    return a < R(0) ? -r : r;
+}
+template <typename R> __device__ __forceinline__ void prox_l1(R x, R& z, R& w, const ProxParamsT<R>& p) {
+    const R u = x + w;
     z = soft(u, p.thr);
     w = u - z;
 }
-__device__ __forceinline__ void prox_cnc(float x, float& z, float& w, const ProxParams& p) {
-    const float u = x + w;
-    const float clipz = fminf(fmaxf(z, -p.ib), p.ib);          // z - soft(z, 1/b)
-    const float t = fmaf(p.c1, z, fmaf(p.c2, u, p.c3 * clipz));
+template <typename R> __device__ __forceinline__ void prox_cnc(R x, R& z, R& w, const ProxParamsT<R>& p) {
+    const R u = x + w;
+    const R clipz = z < -p.ib ? -p.ib : (z > p.ib ? p.ib : z);          // z - soft(z, 1/b)
+    const R t = fma_r(p.c1, z, fma_r(p.c2, u, p.c3 * clipz));
     z = soft(t, p.thr);
     w = u - z;
 }
 
 // ------------------------------------------------------------------------------------------
-// rows
+// rows: one wavefront per row; 4 rows per workgroup (2 in fp64: same LDS footprint)
 // ------------------------------------------------------------------------------------------
-template <int N, int IN, bool INV, int EPI>
-__global__ __launch_bounds__(256) void k_rows(RowArgs p) {
-    constexpr int T = 64, ROWS = 4;
-    __shared__ float2 sA[ROWS * N];
-    __shared__ float2 sB[ROWS * N];
-    __shared__ float2 sTw[N];
+template <typename R> struct RowCfg { static constexpr int ROWS = sizeof(R) == 8 ? 2 : 4; };
+
+template <int N, int IN, bool INV, int EPI, typename R>
+__global__ __launch_bounds__(256) void k_rows(RowArgsT<R> p) {
+    using C = typename CxOf<R>::type;
+    constexpr int T = 64, ROWS = RowCfg<R>::ROWS;
+    __shared__ C sA[ROWS * N];
+    __shared__ C sB[ROWS * N];
+    __shared__ C sTw[N];
     const int tid = threadIdx.x, lane = tid & 63, rw = tid >> 6;
-    const float2* gtw = (N == 256) ? g_tw256 : g_tw512;
-    for (int i = tid; i < N; i += 256) sTw[i] = gtw[i];
+    const C* gtw = Tw<R>::get(N);
+    for (int i = tid; i < N; i += ROWS * 64) sTw[i] = gtw[i];
     const int row = blockIdx.x * ROWS + rw;                    // nrows is a multiple of ROWS
     const size_t base = (size_t)row * N;
-    float2* a = sA + rw * N;
-    float2* b = sB + rw * N;
+    C* a = sA + rw * N;
+    C* b = sB + rw * N;
 #pragma unroll
     for (int i = 0; i < N / T; ++i) {
         const int n = lane + i * T;
-        float2 v;
+        C v;
         if (IN == IN_COMPLEX) v = p.cin[base + n];
-        else if (IN == IN_REAL) v = make_float2(p.rin0[base + n], 0.0f);
-        else v = make_float2(p.rin0[base + n] - p.rin1[base + n], 0.0f);
+        else if (IN == IN_REAL) v = mkc(p.rin0[base + n], R(0));
+        else v = mkc(p.rin0[base + n] - p.rin1[base + n], R(0));
         a[n] = v;
     }
     __syncthreads();
-    float2* r = fft_lds<N, T, INV>(a, b, sTw, lane);
+    C* r = fft_lds<N, T, INV>(a, b, sTw, lane);
 #pragma unroll
     for (int i = 0; i < N / T; ++i) {
         const int n = lane + i * T;
-        const float2 v = r[n];
+        const C v = r[n];
         if (EPI == EPI_COMPLEX) {
-            p.cout[base + n] = make_float2(v.x * p.scale, v.y * p.scale);
+            p.cout[base + n] = mkc(v.x * p.scale, v.y * p.scale);
         } else if (EPI == EPI_ABS_REAL) {
-            p.x_out[base + n] = fabsf(v.x * p.scale);
+            p.x_out[base + n] = fabs(v.x * p.scale);
         } else if (EPI == EPI_ABS_COMPLEX) {
-            p.x_out[base + n] = sqrtf(v.x * v.x + v.y * v.y) * p.scale;
+            p.x_out[base + n] = sqrt(v.x * v.x + v.y * v.y) * p.scale;
         } else {
-            const float x = fabsf(v.x * p.scale);
-            float z = p.z[base + n], w = p.w[base + n];
+            const R x = fabs(v.x * p.scale);
+            R z = p.z[base + n], w = p.w[base + n];
             if (EPI == EPI_L1) prox_l1(x, z, w, p.prox); else prox_cnc(x, z, w, p.prox);
             p.z[base + n] = z;
             p.w[base + n] = w;
@@ -151,14 +173,15 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs p) {
     }
 }
 
-template <int N, int IN, bool INV, int EPI>
-static hipError_t launch_rows_t(hipStream_t s, const RowArgs& a) {
-    hipLaunchKernelGGL((k_rows<N, IN, INV, EPI>), dim3(a.nrows / 4), dim3(256), 0, s, a);
+template <int N, int IN, bool INV, int EPI, typename R>
+static hipError_t launch_rows_t(hipStream_t s, const RowArgsT<R>& a) {
+    constexpr int ROWS = RowCfg<R>::ROWS;
+    hipLaunchKernelGGL((k_rows<N, IN, INV, EPI, R>), dim3(a.nrows / ROWS), dim3(ROWS * 64), 0, s, a);
     return hipGetLastError();
 }
 
-template <int N>
-static hipError_t launch_rows_n(hipStream_t s, RowIn in, bool inv, RowEpi epi, const RowArgs& a) {
+template <int N, typename R>
+static hipError_t launch_rows_n(hipStream_t s, RowIn in, bool inv, RowEpi epi, const RowArgsT<R>& a) {
     if (!inv && epi == EPI_COMPLEX) {
         if (in == IN_COMPLEX)   return launch_rows_t<N, IN_COMPLEX, false, EPI_COMPLEX>(s, a);
         if (in == IN_REAL)      return launch_rows_t<N, IN_REAL, false, EPI_COMPLEX>(s, a);
@@ -176,59 +199,66 @@ static hipError_t launch_rows_n(hipStream_t s, RowIn in, bool inv, RowEpi epi, c
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_rows(hipStream_t s, int W, RowIn in, bool inv, RowEpi epi, const RowArgs& a) {
-    if (a.nrows % 4) return hipErrorInvalidValue;
+template <typename R>
+hipError_t launch_rows(hipStream_t s, int W, RowIn in, bool inv, RowEpi epi, const RowArgsT<R>& a) {
+    if (a.nrows % RowCfg<R>::ROWS) return hipErrorInvalidValue;
     if (W == 256) return launch_rows_n<256>(s, in, inv, epi, a);
     if (W == 512) return launch_rows_n<512>(s, in, inv, epi, a);
     return hipErrorInvalidValue;
 }
+template hipError_t launch_rows<float>(hipStream_t, int, RowIn, bool, RowEpi, const RowArgsT<float>&);
+template hipError_t launch_rows<double>(hipStream_t, int, RowIn, bool, RowEpi, const RowArgsT<double>&);
 
 // ------------------------------------------------------------------------------------------
 // columns: [optional forward] -> pointwise k-space op -> [optional inverse]
+// tile = COLS columns x N rows, COLS = 16 (8 for fp64 at N = 512: LDS), 256/COLS lanes per column
 // ------------------------------------------------------------------------------------------
-template <int N, bool PRE, int MID, bool POST>
-__global__ __launch_bounds__(256) void k_cols(ColArgs p, int W) {
-    constexpr int COLS = 16, T = 16, P = N + 1;
-    extern __shared__ float2 smem[];
-    float2* sA = smem;                  // [COLS][P]
-    float2* sB = smem + COLS * P;
-    float2* sTw = smem + 2 * COLS * P;
+template <int N, typename R> struct ColCfg { static constexpr int COLS = (sizeof(R) == 8 && N == 512) ? 8 : 16; };
+
+template <int N, bool PRE, int MID, bool POST, typename R>
+__global__ __launch_bounds__(256) void k_cols(ColArgsT<R> p, int W) {
+    using C = typename CxOf<R>::type;
+    constexpr int COLS = ColCfg<N, R>::COLS, T = 256 / COLS, P = N + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* sA = reinterpret_cast<C*>(smem_raw);     // [COLS][P]
+    C* sB = sA + COLS * P;
+    C* sTw = sA + 2 * COLS * P;
     const int tid = threadIdx.x;
-    const float2* gtw = (N == 256) ? g_tw256 : g_tw512;
+    const C* gtw = Tw<R>::get(N);
     for (int i = tid; i < N; i += 256) sTw[i] = gtw[i];
     const int tiles = W / COLS;
     const int b = blockIdx.x / tiles;
     const int k0 = (blockIdx.x % tiles) * COLS;
     const size_t sbase = (size_t)b * N * W;
     for (int idx = tid; idx < N * COLS; idx += 256) {
-        const int r = idx >> 4, c = idx & 15;
+        const int r = idx / COLS, c = idx % COLS;
         sA[c * P + r] = p.in[sbase + (size_t)r * W + k0 + c];
     }
     __syncthreads();
-    const int c_f = tid >> 4, t_f = tid & 15;
-    float2* cur = sA;
-    float2* oth = sB;
+    const int c_f = tid / T, t_f = tid % T;
+    C* cur = sA;
+    C* oth = sB;
     if (PRE) {
-        float2* r = fft_lds<N, T, false>(sA + c_f * P, sB + c_f * P, sTw, t_f);
+        C* r = fft_lds<N, T, false>(sA + c_f * P, sB + c_f * P, sTw, t_f);
         if (r != sA + c_f * P) { cur = sB; oth = sA; }
     }
     if (MID != MID_NONE) {
         const int mid = p.mask_id ? p.mask_id[b] : 0;
         const uint8_t* mask = p.mask_bank + (size_t)mid * N * W;
-        const float2* yb = p.y + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
+        const C* yb = p.y + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
         for (int idx = tid; idx < N * COLS; idx += 256) {
-            const int r = idx >> 4, c = idx & 15;
+            const int r = idx / COLS, c = idx % COLS;
             const size_t g = (size_t)r * W + k0 + c;
-            float2 X = cur[c * P + r];
+            C X = cur[c * P + r];
             const bool m = mask[g] != 0;
             if (MID == MID_BLEND) {
-                if (m) { const float2 yv = yb[g]; X.x = fmaf(yv.x - X.x, p.c, X.x); X.y = fmaf(yv.y - X.y, p.c, X.y); }
+                if (m) { const C yv = yb[g]; X.x = fma_r(yv.x - X.x, p.c, X.x); X.y = fma_r(yv.y - X.y, p.c, X.y); }
             } else if (MID == MID_MASK) {
-                if (!m) X = make_float2(0.f, 0.f);
+                if (!m) X = mkc(R(0), R(0));
             } else if (MID == MID_RESID) {
-                if (m) { const float2 yv = yb[g]; X.x -= yv.x; X.y -= yv.y; } else X = make_float2(0.f, 0.f);
+                if (m) { const C yv = yb[g]; X.x -= yv.x; X.y -= yv.y; } else X = mkc(R(0), R(0));
             } else if (MID == MID_MASK_ADD) {
-                const float2 nv = yb[g];
+                const C nv = yb[g];
                 X = m ? cadd(X, nv) : nv;
             }
             cur[c * P + r] = X;
@@ -236,31 +266,33 @@ __global__ __launch_bounds__(256) void k_cols(ColArgs p, int W) {
         __syncthreads();
     }
     if (POST) {
-        float2* r = fft_lds<N, T, true>(cur + c_f * P, oth + c_f * P, sTw, t_f);
-        if (r != cur + c_f * P) { float2* tmp = cur; cur = oth; oth = tmp; }
+        C* r = fft_lds<N, T, true>(cur + c_f * P, oth + c_f * P, sTw, t_f);
+        if (r != cur + c_f * P) { C* tmp = cur; cur = oth; oth = tmp; }
     }
     for (int idx = tid; idx < N * COLS; idx += 256) {
-        const int r = idx >> 4, c = idx & 15;
+        const int r = idx / COLS, c = idx % COLS;
         p.out[sbase + (size_t)r * W + k0 + c] = cur[c * P + r];
     }
 }
 
-template <int N, bool PRE, int MID, bool POST>
-static hipError_t launch_cols_t(hipStream_t s, int W, const ColArgs& a) {
-    const size_t lds = sizeof(float2) * (2 * 16 * (N + 1) + N);
+template <int N, bool PRE, int MID, bool POST, typename R>
+static hipError_t launch_cols_t(hipStream_t s, int W, const ColArgsT<R>& a) {
+    using C = typename CxOf<R>::type;
+    constexpr int COLS = ColCfg<N, R>::COLS;
+    const size_t lds = sizeof(C) * (2 * COLS * (N + 1) + N);
     static bool attr_done = false;          // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_cols<N, PRE, MID, POST>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_cols<N, PRE, MID, POST, R>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_cols<N, PRE, MID, POST>), dim3(a.B * (W / 16)), dim3(256), lds, s, a, W);
+    hipLaunchKernelGGL((k_cols<N, PRE, MID, POST, R>), dim3(a.B * (W / COLS)), dim3(256), lds, s, a, W);
     return hipGetLastError();
 }
 
-template <int N>
-static hipError_t launch_cols_n(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgs& a) {
+template <int N, typename R>
+static hipError_t launch_cols_n(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a) {
     if (pre && !post && mid == MID_NONE)      return launch_cols_t<N, true, MID_NONE, false>(s, W, a);
     if (!pre && post && mid == MID_NONE)      return launch_cols_t<N, false, MID_NONE, true>(s, W, a);
     if (pre && post && mid == MID_BLEND)      return launch_cols_t<N, true, MID_BLEND, true>(s, W, a);
@@ -271,12 +303,15 @@ static hipError_t launch_cols_n(hipStream_t s, int W, bool pre, ColMid mid, bool
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_cols(hipStream_t s, int H, int W, bool pre, ColMid mid, bool post, const ColArgs& a) {
+template <typename R>
+hipError_t launch_cols(hipStream_t s, int H, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a) {
     if (W % 16) return hipErrorInvalidValue;
     if (H == 256) return launch_cols_n<256>(s, W, pre, mid, post, a);
     if (H == 512) return launch_cols_n<512>(s, W, pre, mid, post, a);
     return hipErrorInvalidValue;
 }
+template hipError_t launch_cols<float>(hipStream_t, int, int, bool, ColMid, bool, const ColArgsT<float>&);
+template hipError_t launch_cols<double>(hipStream_t, int, int, bool, ColMid, bool, const ColArgsT<double>&);
 
 // ------------------------------------------------------------------------------------------
 // pointwise kernels on caller pointers (PnP path, S6:301-308): 4 floats per lane, grid-stride

@@ -30,12 +30,20 @@ def _host(a, dtype):
 class Engine:
     """One context per (device, H, W, Bmax).  Not thread-safe, not re-entrant (as the ABI says)."""
 
-    def __init__(self, H=256, W=256, Bmax=1, device=0):
+    def __init__(self, H=256, W=256, Bmax=1, device=0, precision='f32'):
+        """precision='f64' makes an fp64 validation context (generic kernels in double; only
+        upload / init_state / set_state / get_state / admm_l1 / admm_cnc / x are available)."""
+        if precision not in ('f32', 'f64'):
+            raise ValueError("precision must be 'f32' or 'f64'")
         self._L = _lib.lib()
         self._ctx = _lib.ctx_p()
-        _lib.check(self._L.pnp_ctx_create(int(device), int(H), int(W), int(Bmax), C.byref(self._ctx)))
+        self.f64 = precision == 'f64'
+        create = self._L.pnp_ctx_create_f64 if self.f64 else self._L.pnp_ctx_create
+        _lib.check(create(int(device), int(H), int(W), int(Bmax), C.byref(self._ctx)))
         self.H, self.W, self.Bmax, self.device = int(H), int(W), int(Bmax), int(device)
         self.B = 0
+        self._real = np.float64 if self.f64 else np.float32
+        self._cplx = np.complex128 if self.f64 else np.complex64
 
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -99,12 +107,13 @@ class Engine:
         y = np.asarray(y)
         if y.ndim == 2:
             y = y[None]
-        y = _host(y, np.complex64)
+        y = _host(y, self._cplx)
         B = y.shape[0]
         if y.shape[1:] != (self.H, self.W):
             raise ValueError('y shape %s does not match engine %dx%d' % (y.shape[1:], self.H, self.W))
         bank, mid = self._masks(masks, mask_id, B)
-        _lib.check(self._L.pnp_upload_problem(self._ctx, _ptr(y), _ptr(bank), _ptr(mid), B, bank.shape[0], 0))
+        up = self._L.pnp_upload_problem_f64 if self.f64 else self._L.pnp_upload_problem
+        _lib.check(up(self._ctx, _ptr(y), _ptr(bank), _ptr(mid), B, bank.shape[0], 0))
         self.B = B
 
     def synthesize(self, img, noise, masks, mask_id=None):
@@ -133,15 +142,17 @@ class Engine:
         _lib.check(self._L.pnp_init_state(self._ctx))
 
     def set_state(self, z=None, w=None):
-        zz = None if z is None else (z if _is_dev(z) else _host(z, np.float32))
-        ww = None if w is None else (w if _is_dev(w) else _host(w, np.float32))
+        zz = None if z is None else (z if _is_dev(z) else _host(z, self._real))
+        ww = None if w is None else (w if _is_dev(w) else _host(w, self._real))
         dev = 1 if (_is_dev(z) or _is_dev(w)) else 0
-        _lib.check(self._L.pnp_set_state(self._ctx, _ptr(zz), _ptr(ww), dev))
+        fn = self._L.pnp_set_state_f64 if self.f64 else self._L.pnp_set_state
+        _lib.check(fn(self._ctx, _ptr(zz), _ptr(ww), dev))
 
     def get_state(self):
-        z = np.empty((self.B, self.H, self.W), np.float32)
+        z = np.empty((self.B, self.H, self.W), self._real)
         w = np.empty_like(z)
-        _lib.check(self._L.pnp_get_state(self._ctx, _ptr(z), _ptr(w), 0))
+        fn = self._L.pnp_get_state_f64 if self.f64 else self._L.pnp_get_state
+        _lib.check(fn(self._ctx, _ptr(z), _ptr(w), 0))
         return z, w
 
     # -- whole loops ----------------------------------------------------------------------
@@ -155,8 +166,9 @@ class Engine:
         if out is not None and _is_dev(out):
             _lib.check(self._L.pnp_download_x(self._ctx, _ptr(out), 1))
             return out
-        x = np.empty((self.B, self.H, self.W), np.float32)
-        _lib.check(self._L.pnp_download_x(self._ctx, _ptr(x), 0))
+        x = np.empty((self.B, self.H, self.W), self._real)
+        fn = self._L.pnp_download_x_f64 if self.f64 else self._L.pnp_download_x
+        _lib.check(fn(self._ctx, _ptr(x), 0))
         return x
 
     # -- step-wise operators on device tensors (PnP path) ---------------------------------

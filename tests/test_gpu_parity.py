@@ -347,3 +347,66 @@ def test_error_behaviour(P):
             eng.x()                                     # no iteration yet
         with pytest.raises(PnpError):
             eng.admm_l1(1, 0.1, 0.0)                    # reo must be > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's full size (config 2: 512 slices of 256x256, CNC presets) through
+# size-independent properties: slices are independent, so any sub-batch must reproduce the same
+# slices bit for bit, a permutation of the batch permutes the output, and x >= 0 is finite.
+# ------------------------------------------------------------------------------------------------
+def test_full_size_batch_properties(P, golden_inputs):
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    masks = _masks(golden_inputs)
+    B, K = 512, 25
+    img, noise = S.batch(0, B)
+    mid = (np.arange(B) % 3).astype(np.int32)
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.synthesize(img, noise, masks, mid)
+        y = eng.download_y()
+        eng.init_state()
+        eng.admm_cnc(K, 0.45, 0.5, 0.05, 64)
+        x = eng.x()
+        # (1) permuted batch -> permuted output (pairs of slices share a complex transform, so this
+        #     also shows that the pairing never leaks one slice into its partner beyond round-off:
+        #     partners change under the permutation, results may move by fp32 round-off only)
+        perm = np.random.default_rng(0).permutation(B)
+        eng.upload(y[perm], masks, mid[perm])
+        eng.init_state()
+        eng.admm_cnc(K, 0.45, 0.5, 0.05, 64)
+        xp = eng.x()
+    assert np.isfinite(x).all() and x.min() >= 0
+    sel = [0, 1, 255, 256, 511]
+    for b in sel:
+        pos = int(np.flatnonzero(perm == b)[0])
+        assert rel_l2(xp[pos], x[b]) <= 2e-5, b
+    # (2) the same slices in a batch of 6, same pairing -> bit-identical
+    with P.Engine(256, 256, Bmax=6) as eng:
+        sub = [0, 1, 254, 255, 510, 511]
+        eng.upload(y[sub], masks, mid[sub])
+        eng.init_state()
+        eng.admm_cnc(K, 0.45, 0.5, 0.05, 64)
+        xs = eng.x()
+    assert np.array_equal(xs, x[sub])
+    # (3) spot-check against the oracle
+    for b in (0, 511):
+        ref = O.admm_cnc(y[b].astype(np.complex128), masks[mid[b]], K)
+        assert rel_l2(x[b], ref) <= 1e-5, b
+
+
+def test_odd_batch_and_padding_slice(P, golden_inputs):
+    """B odd: the last slice has no partner in its complex transform; its result must equal the
+    result it gets with a partner present (round-off) and the oracle."""
+    masks = _masks(golden_inputs)
+    imgs, ys, mid = _synthetic(4, masks)
+    with P.Engine(256, 256, Bmax=4) as eng:
+        eng.upload(ys[:3], masks, mid[:3])
+        eng.init_state()
+        eng.admm_l1(20, 0.1, 0.015)
+        x3 = eng.x()
+        eng.upload(ys, masks, mid)
+        eng.init_state()
+        eng.admm_l1(20, 0.1, 0.015)
+        x4 = eng.x()
+    assert np.array_equal(x3[:2], x4[:2])
+    assert rel_l2(x3[2], x4[2]) <= 2e-6
+    assert rel_l2(x3[2], O.admm_l1(ys[2].astype(np.complex64).astype(np.complex128), masks[mid[2]], 20)) <= 1e-5
