@@ -82,6 +82,7 @@ struct FRowArgs {
     int B;
     float scale;
     ProxCoef prox;
+    int u_first;
 };
 
 // physical column of k-space column k inside a row of T: mirrored columns sit side by side so the
@@ -113,7 +114,11 @@ __device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32* twl, c32* re
     fft256_tail<INV>(a);
 }
 
-// PROX: 0 none, 1 L1, 2 CNC
+// PROX: 0 none, 1 L1, 2 CNC, 3 L1 in single-state form: for L1, z = soft(u) and w = u - z are both
+// functions of u = x + w_old, so between the first and the last iteration of a run only u is kept
+// (in the w buffer): 8 N instead of 16 N state bytes per slice-iteration.  w_old is recomputed as
+// u - soft(u) -- the very expression that produces the stored w -- so results are bit-identical
+// to the two-state form.  p.u_first = 1 while the w buffer still holds a genuine w.
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
     __shared__ __attribute__((aligned(16))) c32 lds[16 * XP + 256];
@@ -158,7 +163,38 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
             xa[3] = fabsf(c23.z) * p.scale; xb[3] = fabsf(c23.w) * p.scale;
         }
         float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
-        if (PROX != 0 || !HAS_INV) {
+        if (PROX == 3) {
+            const float4 q1 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * 65536 + off);
+            wa[0] = q1.x; wa[1] = q1.y; wa[2] = q1.z; wa[3] = q1.w;
+            if (has_b) {
+                const float4 q2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * 65536 + off);
+                wb[0] = q2.x; wb[1] = q2.y; wb[2] = q2.z; wb[3] = q2.w;
+            }
+            float ua[4], ub[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!p.u_first) {                        // buffer holds u_old: w_old = u_old - soft(u_old)
+                    wa[q] = wa[q] - soft_thr(wa[q], p.prox.thr);
+                    wb[q] = wb[q] - soft_thr(wb[q], p.prox.thr);
+                }
+                ua[q] = xa[q] + wa[q];
+                ub[q] = xb[q] + wb[q];
+                za[q] = soft_thr(ua[q], p.prox.thr); wa[q] = ua[q] - za[q];
+                zb[q] = soft_thr(ub[q], p.prox.thr); wb[q] = ub[q] - zb[q];
+            }
+            if (HAS_FWD) {                               // mid-run: keep only u
+                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * 65536 + off) = make_float4(ua[0], ua[1], ua[2], ua[3]);
+                if (has_b) *reinterpret_cast<float4*>(p.w_out + (size_t)sb * 65536 + off) = make_float4(ub[0], ub[1], ub[2], ub[3]);
+            } else {                                     // end of run: materialise z and w
+                *reinterpret_cast<float4*>(p.z_out + (size_t)sa * 65536 + off) = make_float4(za[0], za[1], za[2], za[3]);
+                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * 65536 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
+                if (has_b) {
+                    *reinterpret_cast<float4*>(p.z_out + (size_t)sb * 65536 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
+                    *reinterpret_cast<float4*>(p.w_out + (size_t)sb * 65536 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
+                }
+            }
+        }
+        if ((PROX != 0 && PROX != 3) || !HAS_INV) {
             const float4 v1 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sa * 65536 + off);
             const float4 v2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * 65536 + off);
             za[0] = v1.x; za[1] = v1.y; za[2] = v1.z; za[3] = v1.w;
@@ -170,7 +206,7 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
                 wb[0] = v4.x; wb[1] = v4.y; wb[2] = v4.z; wb[3] = v4.w;
             }
         }
-        if (PROX != 0) {
+        if (PROX == 1 || PROX == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], p.prox); prox_l1_pt(xb[q], zb[q], wb[q], p.prox); }
@@ -387,14 +423,18 @@ hipError_t fused256_run(Fused256* f, hipStream_t s, float* z, float* w, float* x
         FRowArgs a;
         a.T = f->T + (size_t)pair0 * 65536;
         a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
-        a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp);
+        a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp); a.u_first = 1;
+        static int two_state = -1;              // PNP_FUSED_L1_TWO_STATE=1: test hook, keeps z and w every iteration
+        if (two_state < 0) { const char* ev = getenv("PNP_FUSED_L1_TWO_STATE"); two_state = ev ? atoi(ev) : 0; }
         e = launch_frows<false, 0, true, false>(s, np, a);
         for (int i = 0; i < iters && e == hipSuccess; ++i) {
             e = launch_fcols(f, s, pair0, np, dc_c);
             if (e != hipSuccess) break;
             const bool last = (i == iters - 1);
-            if (cnc) e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
-            else     e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+            a.u_first = (i == 0);
+            if (cnc)            e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
+            else if (two_state) e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+            else                e = last ? launch_frows<true, 3, false, true>(s, np, a) : launch_frows<true, 3, true, false>(s, np, a);
         }
     }
     return e;
@@ -404,7 +444,7 @@ hipError_t fused256_dc(Fused256* f, hipStream_t s, const float* z, const float* 
     const int np = (B + 1) / 2;
     FRowArgs a;
     a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = nullptr; a.w_out = nullptr; a.x_out = x; a.B = B;
-    a.scale = 1.0f / 65536.0f; a.prox = ProxCoef{};
+    a.scale = 1.0f / 65536.0f; a.prox = ProxCoef{}; a.u_first = 1;
     hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
     if (e == hipSuccess) e = launch_fcols(f, s, 0, np, dc_c);
     if (e == hipSuccess) e = launch_frows<true, 0, false, true>(s, np, a);

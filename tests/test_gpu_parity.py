@@ -410,3 +410,31 @@ def test_odd_batch_and_padding_slice(P, golden_inputs):
     assert np.array_equal(x3[:2], x4[:2])
     assert rel_l2(x3[2], x4[2]) <= 2e-6
     assert rel_l2(x3[2], O.admm_l1(ys[2].astype(np.complex64).astype(np.complex128), masks[mid[2]], 20)) <= 1e-5
+
+
+def test_l1_single_state_form_is_bit_identical(P, golden_inputs):
+    """ADMM_L1's fused loop keeps only u = x + w between iterations (z = soft(u), w = u - z); the
+    PNP_FUSED_L1_TWO_STATE=1 hook keeps z and w.  Same bits, and the state handed back is the
+    genuine (z, w) pair."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import pnp_admm_cnc_mri_amd as P\n"
+        "from pnp_admm_cnc_mri_amd import synthetic as S\n"
+        "m = S.reference_masks(); masks = np.stack([m['Q_Random30'], m['Q_Radial30']]).astype(np.uint8)\n"
+        "img, noise = S.batch(0, 5)\n"
+        "eng = P.Engine(256, 256, Bmax=5); eng.synthesize(img, noise, masks, np.arange(5) %% 2); eng.init_state()\n"
+        "eng.admm_l1(7, 0.1, 0.015); x1 = eng.x(); z1, w1 = eng.get_state()\n"
+        "eng.admm_l1(1, 0.1, 0.015); eng.admm_l1(4, 0.1, 0.015); x2 = eng.x(); z2, w2 = eng.get_state()\n"
+        "np.savez(sys.argv[1], x1=x1, z1=z1, w1=w1, x2=x2, z2=z2, w2=w2)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for flag in ('0', '1'):
+        path = '/tmp/l1_state_%s.npz' % flag
+        subprocess.check_call([sys.executable, '-c', code, path], env=dict(os.environ, PNP_FUSED_L1_TWO_STATE=flag))
+        outs.append(np.load(path))
+    for k in ('x1', 'z1', 'w1', 'x2', 'z2', 'w2'):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    # z = soft(u), w = u - z with u = z + w: w is clipped to the threshold
+    assert np.abs(outs[0]['w2']).max() <= 0.1 * 0.015 + 1e-6     # u - fl(u - thr): thr up to an ulp of u
