@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
+    ap.add_argument('--channels-last', action='store_true')
     args = ap.parse_args()
     fam = D.family(args.model)
     mname = args.mask or {'ffdnet': 'Q_Radial30', 'drunet': 'Q_Cartesian30'}.get(fam, 'Q_Random30')
@@ -39,6 +40,8 @@ def main():
     sig = None
     if sched:
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
     den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch).to(dev)
     eng = P.Engine(256, 256, Bmax=B)
     eng.synthesize(img, noise, mask)

@@ -233,7 +233,7 @@ class Denoiser:
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
 
     def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
-                 cnn_batch=64):
+                 cnn_batch=64, channels_last=True):
         self.name, self.fam = model_name, family(model_name)
         self.model = model
         self.noise_level_model = noise_level_model
@@ -242,6 +242,7 @@ class Denoiser:
         self.bank = bank                  # ircnn: {str(idx): state_dict}
         self.former_idx = 0
         self.cnn_batch = cnn_batch
+        self.channels_last = channels_last        # NHWC weights/activations: MIOpen's faster fp32 conv path (+9 %)
         self.noise_map = None
         if self.fam == 'fdncnn':
             if noises is None:
@@ -251,6 +252,8 @@ class Denoiser:
 
     def to(self, device):
         self.model = self.model.to(device)
+        if self.channels_last and torch.device(device).type == 'cuda':
+            self.model = self.model.to(memory_format=torch.channels_last)
         if self.sigmas is not None:
             self.sigmas = self.sigmas.to(device)
         if self.noise_map is not None:

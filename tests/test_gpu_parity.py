@@ -438,3 +438,76 @@ def test_l1_single_state_form_is_bit_identical(P, golden_inputs):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     # z = soft(u), w = u - z with u = z + w: w is clipped to the threshold
     assert np.abs(outs[0]['w2']).max() <= 0.1 * 0.015 + 1e-6     # u - fl(u - thr): thr up to an ulp of u
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases of the boundary
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fast', [0, 1])
+def test_degenerate_masks(P, torch, fast):
+    """all-zero mask: the k-space blend is the identity, so x = |z - w| exactly up to FFT round-off;
+    all-one mask: every point is blended; both against the oracle."""
+    rng = np.random.default_rng(3)
+    B = 2
+    y = (rng.standard_normal((B, 256, 256)) + 1j * rng.standard_normal((B, 256, 256))).astype(np.complex64) * 50
+    z = rng.uniform(0, 1, (B, 256, 256)).astype(np.float32)
+    w = rng.uniform(-0.2, 0.2, (B, 256, 256)).astype(np.float32)
+    masks = np.stack([np.zeros((256, 256), np.uint8), np.ones((256, 256), np.uint8)])
+    mid = np.array([0, 1], np.int32)
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.set_fast_path(fast)
+        eng.upload(y, masks, mid)
+        x = P.utils_pnp.dc_solve(eng, torch.from_numpy(z).cuda(), torch.from_numpy(w).cuda(), 0.3).cpu().numpy()
+    assert np.abs(x[0] - np.abs(z[0] - w[0])).max() <= 2e-6
+    ref = O.dc_step(z[1].astype(np.float64), w[1].astype(np.float64), y[1].astype(np.complex128), masks[1], 0.3)
+    assert rel_l2(x[1], ref) <= 2e-6
+
+
+def test_context_reuse_across_problems(P, golden_inputs):
+    """One ctx, several uploads with different B / masks / solvers; zero iterations is a no-op."""
+    masks = _masks(golden_inputs)
+    imgs, ys, mid = _synthetic(6, masks)
+    with P.Engine(256, 256, Bmax=6) as eng:
+        for B in (6, 1, 4):
+            eng.upload(ys[:B], masks, mid[:B])
+            eng.init_state()
+            z0, w0 = eng.get_state()
+            eng.admm_l1(0, 0.1, 0.015)
+            z1, w1 = eng.get_state()
+            assert np.array_equal(z0, z1) and np.array_equal(w0, w1)
+            eng.admm_l1(3, 0.1, 0.015)
+            x = eng.x()
+            assert x.shape == (B, 256, 256)
+            for b in range(B):
+                ref = O.admm_l1(ys[b].astype(np.complex64).astype(np.complex128), masks[mid[b]], 3)
+                assert rel_l2(x[b], ref) <= 2e-6
+        # a single mask for all slices (mask_id = None) and a 2-D mask argument
+        eng.upload(ys[:2], masks[1])
+        eng.init_state()
+        eng.admm_cnc(2, 0.45, 0.5, 0.05, 64)
+        ref = O.admm_cnc(ys[1].astype(np.complex64).astype(np.complex128), masks[1], 2)
+        assert rel_l2(eng.x()[1], ref) <= 2e-6
+
+
+def test_prox_edge_values(P, torch):
+    """thresholds at and around the kinks: exact zeros, +-threshold, +-1/b, negative inputs."""
+    B = 1
+    vals = np.array([0.0, 1e-9, -1e-9, 0.0015, -0.0015, 0.00150001, 1 / 64, -1 / 64, 0.5, -0.5, 1.0, 2.0], np.float32)
+    x = np.zeros((B, 256, 256), np.float32)
+    z = np.zeros_like(x)
+    w = np.zeros_like(x)
+    n = len(vals)
+    grid = np.stack(np.meshgrid(vals, vals, vals, indexing='ij'), -1).reshape(-1, 3)
+    x.reshape(-1)[:len(grid)] = np.abs(grid[:, 0])
+    z.reshape(-1)[:len(grid)] = grid[:, 1]
+    w.reshape(-1)[:len(grid)] = grid[:, 2]
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.upload(np.zeros((B, 256, 256), np.complex64), np.ones((256, 256), np.uint8))
+        tx, tz, tw = (torch.from_numpy(a.copy()).cuda() for a in (x, z, w))
+        P.utils_pnp.prox_l1(eng, tx, tz, tw, 0.0015)
+        zr, wr = O.l1_step(x.astype(np.float64), z.astype(np.float64), w.astype(np.float64), 0.1, 0.015)
+        assert np.abs(tz.cpu().numpy() - zr).max() <= 3e-7 and np.abs(tw.cpu().numpy() - wr).max() <= 3e-7
+        tx, tz, tw = (torch.from_numpy(a.copy()).cuda() for a in (x, z, w))
+        P.utils_pnp.prox_cnc(eng, tx, tz, tw, 0.45, 0.5, 0.05, 64)
+        zr, wr = O.cnc_step(x.astype(np.float64), z.astype(np.float64), w.astype(np.float64), 0.45, 0.5, 0.05, 64)
+        assert np.abs(tz.cpu().numpy() - zr).max() <= 1e-6 and np.abs(tw.cpu().numpy() - wr).max() <= 1e-6

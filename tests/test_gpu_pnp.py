@@ -54,7 +54,8 @@ def test_pnp_admm_cnc_d_golden(env, golden_inputs, name, tmp_path):
     assert len(out) == 22 and out[0].shape == (256, 256)
     assert rel_l2(out[0], ref) <= 2e-4, rel_l2(out[0], ref)
     assert _psnr_close(out[0], ref, golden_inputs['gray'])
-    assert abs(psnr1[0] - O.calculate_psnr(np.round(out[0] * 255), golden_inputs['gray'])) <= 1e-6
+    # device PSNR of the uint8-quantised image (S6:314); float32 vs float64 rounding of x*255 may flip a pixel at .5
+    assert abs(psnr1[0] - O.calculate_psnr(np.round(out[0] * 255), golden_inputs['gray'])) <= 1e-4
 
 
 def test_pnp_admm_cnc_dncnn_pair_golden(env, golden_inputs, tmp_path):
