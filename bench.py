@@ -67,6 +67,8 @@ def main():
     ap.add_argument('--generic', action='store_true', help='force the generic (unfused) kernels')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--rehearse-gloo', action='store_true',
+                    help='rehearsal of the N>1 launch path on a box with ONE GPU: gloo backend, all ranks on cuda:0')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -81,12 +83,17 @@ def main():
     import pnp_admm_cnc_mri_amd as P
     from pnp_admm_cnc_mri_amd import synthetic as S
 
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     B = args.batch
     mk = S.reference_masks()
@@ -132,11 +139,13 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        x_all = sharding.gather_slices(x_dev, world * B, dst=0)       # one direct RCCL gather over xGMI
-        torch.cuda.synchronize()
+        x_all = sharding.gather_slices(x_dev.cpu() if args.rehearse_gloo else x_dev, world * B, dst=0)
+        torch.cuda.synchronize()                                      # ^ one direct RCCL gather over xGMI
         gather_ms = (time.perf_counter() - tg) * 1e3
         assert (x_all is not None) == (rank == 0)
-        t = torch.tensor([wall_ms, ev_ms, gather_ms], dtype=torch.float64, device='cuda')
+        if rank == 0:
+            assert tuple(x_all.shape) == (world * B, H, W) and torch.equal(x_all[:B].to(x_dev.device), x_dev)
+        t = torch.tensor([wall_ms, ev_ms, gather_ms], dtype=torch.float64, device='cpu' if args.rehearse_gloo else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_ms, ev_ms, gather_ms = (float(v) for v in t.cpu())
     checksum = float(x_dev.double().sum())
