@@ -175,14 +175,16 @@ def main():
             'config': {'workload': 'ADMM_%s, %d synthetic 256x256 complex64 slices per GPU, Q_Random30, S4:176 presets'
                                    % (args.solver.upper(), B),
                        'slices_per_gpu': B, 'path': eng.path_name,
-                       'kernels_per_iteration': eng.kernels_per_iteration},
+                       'queues': int(os.environ.get('PNP_FUSED_STREAMS', '2')) if eng.path_name == 'fused' else 1,
+                       'mixed_row_col_launches': (os.environ.get('PNP_FUSED_SCHED', '1') == '1') if eng.path_name == 'fused' else False},
             'slice_iterations_per_s': value * B_PER_GPU,
             'hip_event_ms_per_step': ev_ms / K,
             'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'note': 'achieved = 57*H*W*B algorithmic bytes per iteration / HIP-event time per iteration '
-                                 '(all kernels of one iteration); traffic = measured HBM bytes per iteration'},
+                                 '(all launches of one iteration; with 2 queues they overlap pairwise, so rocprof kernel '
+                                 'durations sum to ~2x this time); traffic = PMC-measured HBM bytes per iteration'},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)

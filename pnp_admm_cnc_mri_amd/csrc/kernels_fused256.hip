@@ -32,6 +32,13 @@ struct Fused256 {
     c32* T = nullptr;
     float4* Yh = nullptr;
     unsigned long long* Mh = nullptr;
+    // extra queues: parts of the batch run their whole K-iteration chains concurrently, so the
+    // bandwidth-bound row kernel of one part fills the memory-idle phases of another part's
+    // column kernel (slices are independent; results do not depend on the split)
+    static constexpr int MAXQ = 4;
+    hipStream_t side[MAXQ - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[MAXQ - 1] = {nullptr, nullptr, nullptr};
 };
 
 static inline ProxCoef to_coef(const ProxParams& p) {
@@ -119,13 +126,14 @@ __device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32* twl, c32* re
 // (in the w buffer): 8 N instead of 16 N state bytes per slice-iteration.  w_old is recomputed as
 // u - soft(u) -- the very expression that produces the stored w -- so results are bit-identical
 // to the two-state form.  p.u_first = 1 while the w buffer still holds a genuine w.
+constexpr int ROWS_LDS = 16 * XP + 256;      // c32 elements of LDS the row body needs
+
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
-    __shared__ __attribute__((aligned(16))) c32 lds[16 * XP + 256];
+__device__ __forceinline__ void frows_body(const FRowArgs& p, const int bid, c32* lds) {
     const int tid = threadIdx.x, g = tid >> 4, t = tid & 15;
     c32* twl = lds + 16 * XP;                  // W256 table (read where used, not held in VGPRs)
     twl[tid] = g_twf[tid];
-    const int pair = blockIdx.x >> 4, r0 = (blockIdx.x & 15) * 16;
+    const int pair = bid >> 4, r0 = (bid & 15) * 16;
     const int sa = 2 * pair, sb = sa + 1;
     const bool has_b = sb < p.B;
     c32 a[16];
@@ -247,6 +255,12 @@ __global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
     }
 }
 
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
+    __shared__ __attribute__((aligned(16))) c32 lds[ROWS_LDS];
+    frows_body<HAS_INV, PROX, HAS_FWD, WRITE_X>(p, blockIdx.x, lds);
+}
+
 // ------------------------------------------------------------------------------------------
 // columns
 // ------------------------------------------------------------------------------------------
@@ -269,11 +283,12 @@ __device__ __forceinline__ void col_exchange(c32 (&a)[16], c32* region, int t) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
-    __shared__ c32 lds[16 * CP + 256];
+constexpr int COLS_LDS = 16 * CP + 256;
+
+__device__ __forceinline__ void fcols_body(const FColArgs& p, const int bid, c32* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kl = lane & 15, t = 4 * wv + (lane >> 4);
-    const int pair = blockIdx.x / 9, m = blockIdx.x % 9;
+    const int pair = bid / 9, m = bid % 9;
     // tiles 0..7: column pairs q = 16 m + kl (q >= 1) = physical columns (2q, 2q+1);
     // tile 8: the two self-mirrored columns 0 and 128 (physical 0 and 1), one lane group each.
     const bool self = (m == 8);
@@ -335,6 +350,35 @@ __global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_fcols(FColArgs p) {
+    __shared__ __attribute__((aligned(16))) c32 lds[COLS_LDS];
+    fcols_body(p, blockIdx.x, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// mixed launch: ONE grid that holds the row workgroups of one half of the batch and the column
+// workgroups of the other half, dealt 16 : 9 so that every CU hosts both kinds at once.  The row
+// body streams at the HBM rate while the column body has memory-idle phases (operand latency,
+// FFT arithmetic, barriers); co-resident, the two fill each other's gaps -- deterministically,
+// instead of hoping two HIP queues interleave.  nR = 16 * pairs(rows half), nC = 9 * pairs(cols half).
+// ------------------------------------------------------------------------------------------
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__global__ __launch_bounds__(256) void k_fmixed(FRowArgs pr, FColArgs pc, int nR, int nC) {
+    __shared__ __attribute__((aligned(16))) c32 lds[ROWS_LDS > COLS_LDS ? ROWS_LDS : COLS_LDS];
+    const int b = blockIdx.x, g = b / 25, r = b % 25;
+    // groups of 25 consecutive blocks = 16 row + 9 column workgroups while both kinds last
+    const int full = (nR / 16 < nC / 9) ? nR / 16 : nC / 9;
+    int rid = -1, cid = -1;
+    if (g < full) {
+        if (r < 16) rid = g * 16 + r; else cid = g * 9 + (r - 16);
+    } else {
+        const int rest = b - full * 25;                  // leftovers of the longer kind
+        if (nR > full * 16) rid = full * 16 + rest; else cid = full * 9 + rest;
+    }
+    if (rid >= 0) { if (rid < nR) frows_body<HAS_INV, PROX, HAS_FWD, WRITE_X>(pr, rid, lds); }
+    else if (cid < nC) fcols_body(pc, cid, lds);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -367,6 +411,11 @@ void fused256_destroy(Fused256* f) {
     if (f->T) (void)hipFree(f->T);
     if (f->Yh) (void)hipFree(f->Yh);
     if (f->Mh) (void)hipFree(f->Mh);
+    for (int q = 0; q < Fused256::MAXQ - 1; ++q) {
+        if (f->side[q]) (void)hipStreamDestroy(f->side[q]);
+        if (f->ev_join[q]) (void)hipEventDestroy(f->ev_join[q]);
+    }
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     delete f;
 }
 
@@ -385,12 +434,17 @@ static hipError_t launch_frows(hipStream_t s, int np, const FRowArgs& a) {
     return hipGetLastError();
 }
 
-static hipError_t launch_fcols(Fused256* f, hipStream_t s, int pair0, int np, float c) {
+static FColArgs col_args(Fused256* f, int pair0, float c) {
     FColArgs a;
     a.T = f->T + (size_t)pair0 * 65536;
     a.Yh = f->Yh + (size_t)pair0 * YH_PAIR;
     a.Mh = f->Mh + (size_t)pair0 * MH_PAIR;
     a.c = c;
+    return a;
+}
+
+static hipError_t launch_fcols(Fused256* f, hipStream_t s, int pair0, int np, float c) {
+    const FColArgs a = col_args(f, pair0, c);
     hipLaunchKernelGGL(k_fcols, dim3(np * 9), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -411,32 +465,136 @@ static int fused_chunk(int B) {
     return c;
 }
 
+// K iterations on slices [c0, c0+Bc) enqueued on stream s
+static hipError_t run_chunk(Fused256* f, hipStream_t s, float* z, float* w, float* x, int c0, int Bc, int iters,
+                            bool cnc, float dc_c, const ProxParams& pp) {
+    const int np = (Bc + 1) / 2, pair0 = c0 / 2;
+    const size_t so = (size_t)c0 * 65536;
+    FRowArgs a;
+    a.T = f->T + (size_t)pair0 * 65536;
+    a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
+    a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp); a.u_first = 1;
+    static int two_state = -1;              // PNP_FUSED_L1_TWO_STATE=1: test hook, keeps z and w every iteration
+    if (two_state < 0) { const char* ev = getenv("PNP_FUSED_L1_TWO_STATE"); two_state = ev ? atoi(ev) : 0; }
+    hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) {
+        e = launch_fcols(f, s, pair0, np, dc_c);
+        if (e != hipSuccess) break;
+        const bool last = (i == iters - 1);
+        a.u_first = (i == 0);
+        if (cnc)            e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
+        else if (two_state) e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+        else                e = last ? launch_frows<true, 3, false, true>(s, np, a) : launch_frows<true, 3, true, false>(s, np, a);
+    }
+    return e;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static FRowArgs row_args(Fused256* f, float* z, float* w, float* x, int c0, int Bc, const ProxParams& pp) {
+    const size_t so = (size_t)c0 * 65536;
+    FRowArgs a;
+    a.T = f->T + (size_t)(c0 / 2) * 65536;
+    a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
+    a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp); a.u_first = 1;
+    return a;
+}
+
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+static hipError_t launch_mixed_t(hipStream_t s, const FRowArgs& ra, int npR, const FColArgs& ca, int npC) {
+    const int nR = npR * 16, nC = npC * 9;
+    hipLaunchKernelGGL((k_fmixed<HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(nR + nC), dim3(256), 0, s, ra, ca, nR, nC);
+    return hipGetLastError();
+}
+
+// kind: 0 = first (forward only), 1 = mid, 2 = last;  prox: 1 L1 two-state, 2 CNC, 3 L1 single-state
+static hipError_t launch_mixed(hipStream_t s, int kind, int prox, const FRowArgs& ra, int npR, const FColArgs& ca, int npC) {
+    if (kind == 0) return launch_mixed_t<false, 0, true, false>(s, ra, npR, ca, npC);
+    if (kind == 1) {
+        if (prox == 2) return launch_mixed_t<true, 2, true, false>(s, ra, npR, ca, npC);
+        if (prox == 3) return launch_mixed_t<true, 3, true, false>(s, ra, npR, ca, npC);
+        return launch_mixed_t<true, 1, true, false>(s, ra, npR, ca, npC);
+    }
+    if (prox == 2) return launch_mixed_t<true, 2, false, true>(s, ra, npR, ca, npC);
+    if (prox == 3) return launch_mixed_t<true, 3, false, true>(s, ra, npR, ca, npC);
+    return launch_mixed_t<true, 1, false, true>(s, ra, npR, ca, npC);
+}
+static hipError_t launch_rows_kind(hipStream_t s, int kind, int prox, const FRowArgs& ra, int np) {
+    if (kind == 0) return launch_frows<false, 0, true, false>(s, np, ra);
+    if (kind == 1) {
+        if (prox == 2) return launch_frows<true, 2, true, false>(s, np, ra);
+        if (prox == 3) return launch_frows<true, 3, true, false>(s, np, ra);
+        return launch_frows<true, 1, true, false>(s, np, ra);
+    }
+    if (prox == 2) return launch_frows<true, 2, false, true>(s, np, ra);
+    if (prox == 3) return launch_frows<true, 3, false, true>(s, np, ra);
+    return launch_frows<true, 1, false, true>(s, np, ra);
+}
+
+// Staggered schedule over two halves A, B of the batch (slices are independent):
+//   F(A) | C0(A)+F(B) | R0(A)+C0(B) | C1(A)+R0(B) | ... | R_{K-1}(A)+C_{K-1}(B) | R_{K-1}(B)
+// every '+' is ONE mixed launch (k_fmixed): row workgroups of one half next to column workgroups
+// of the other half on every CU.  Same arithmetic per slice as the sequential schedule: bit-identical.
+static hipError_t run_mixed(Fused256* f, hipStream_t s, float* z, float* w, float* x, int c0, int B, int iters,
+                            int prox, float dc_c, const ProxParams& pp) {
+    const int BA = ((B / 2) + 1) & ~1, BB = B - BA;
+    const int npA = BA / 2, npB = (BB + 1) / 2;
+    FRowArgs ra = row_args(f, z, w, x, c0, BA, pp), rb = row_args(f, z, w, x, c0 + BA, BB, pp);
+    const FColArgs ca = col_args(f, c0 / 2, dc_c), cb = col_args(f, c0 / 2 + npA, dc_c);
+    hipError_t e = launch_rows_kind(s, 0, prox, ra, npA);                         // F(A)
+    if (e == hipSuccess) e = launch_mixed(s, 0, prox, rb, npB, ca, npA);           // C0(A) + F(B)
+    for (int i = 0; i < iters && e == hipSuccess; ++i) {
+        const bool last = (i == iters - 1);
+        ra.u_first = rb.u_first = (i == 0);
+        e = launch_mixed(s, last ? 2 : 1, prox, ra, npA, cb, npB);                 // R_i(A) + C_i(B)
+        if (e != hipSuccess) break;
+        if (!last) e = launch_mixed(s, 1, prox, rb, npB, ca, npA);                 // C_{i+1}(A) + R_i(B)
+        else       e = launch_rows_kind(s, 2, prox, rb, npB);                      // R_{K-1}(B)
+    }
+    return e;
+}
+
 hipError_t fused256_run(Fused256* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
                         float dc_c, ProxParams pp) {
     if (iters <= 0) return hipSuccess;
+    static int sched = -1, two_state_l1 = -1;
+    if (sched < 0) sched = env_int("PNP_FUSED_SCHED", 1);                // 1 = mixed launches (default), 0 = sequential
+    if (two_state_l1 < 0) two_state_l1 = env_int("PNP_FUSED_L1_TWO_STATE", 0);
+    static int streams = -1;
+    if (streams < 0) streams = env_int("PNP_FUSED_STREAMS", 2);        // HIP queues the batch is split over
+    const int prox = cnc ? 2 : (two_state_l1 ? 1 : 3);
+    if (sched == 1 && B >= 64 && streams < 2) return run_mixed(f, s, z, w, x, 0, B, iters, prox, dc_c, pp);
+    if (streams > Fused256::MAXQ) streams = Fused256::MAXQ;
+    if (streams >= 2 && B >= 32 * streams) {
+        hipError_t e = hipSuccess;
+        if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
+        for (int q = 0; q < streams - 1 && e == hipSuccess; ++q) {
+            if (f->side[q]) continue;
+            e = hipStreamCreateWithFlags(&f->side[q], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join[q], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(f->ev_fork, s);
+        int c0 = 0;
+        for (int q = 0; q < streams && e == hipSuccess; ++q) {
+            int Bq = (q == streams - 1) ? (B - c0) : (((B / streams) + 1) & ~1);     // even-sized parts
+            hipStream_t sq = (q == 0) ? s : f->side[q - 1];
+            if (q > 0) e = hipStreamWaitEvent(sq, f->ev_fork, 0);
+            if (e == hipSuccess) e = (sched == 1 && Bq >= 64) ? run_mixed(f, sq, z, w, x, c0, Bq, iters, prox, dc_c, pp)
+                                                              : run_chunk(f, sq, z, w, x, c0, Bq, iters, cnc, dc_c, pp);
+            if (q > 0 && e == hipSuccess) e = hipEventRecord(f->ev_join[q - 1], sq);
+            if (q > 0 && e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join[q - 1], 0);
+            c0 += Bq;
+        }
+        return e;
+    }
     const int chunk = fused_chunk(B);
     hipError_t e = hipSuccess;
-    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk) {
-        const int Bc = (B - c0 < chunk) ? (B - c0) : chunk;
-        const int np = (Bc + 1) / 2, pair0 = c0 / 2;
-        const size_t so = (size_t)c0 * 65536;
-        FRowArgs a;
-        a.T = f->T + (size_t)pair0 * 65536;
-        a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
-        a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp); a.u_first = 1;
-        static int two_state = -1;              // PNP_FUSED_L1_TWO_STATE=1: test hook, keeps z and w every iteration
-        if (two_state < 0) { const char* ev = getenv("PNP_FUSED_L1_TWO_STATE"); two_state = ev ? atoi(ev) : 0; }
-        e = launch_frows<false, 0, true, false>(s, np, a);
-        for (int i = 0; i < iters && e == hipSuccess; ++i) {
-            e = launch_fcols(f, s, pair0, np, dc_c);
-            if (e != hipSuccess) break;
-            const bool last = (i == iters - 1);
-            a.u_first = (i == 0);
-            if (cnc)            e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
-            else if (two_state) e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
-            else                e = last ? launch_frows<true, 3, false, true>(s, np, a) : launch_frows<true, 3, true, false>(s, np, a);
-        }
-    }
+    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
+        e = run_chunk(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, cnc, dc_c, pp);
     return e;
 }
 

@@ -18,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'gpurun_out')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+update_traffic = '--no-traffic' not in sys.argv
 
 
 def short(name):
@@ -61,10 +62,15 @@ out = {'tag': tag, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench
                               '(+ separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with --steps 20 --warmup 2)',
        'kernel_stats': stats, 'pmc': pmc, 'bench_line_under_profiler': bench}
 iter_kernels = [s for s in stats if s['calls'] >= 50]
+steps = (bench or {}).get('steps', 100) + (bench or {}).get('warmup', 10)
 out['per_iteration'] = {
     'kernels': [s['kernel'] for s in iter_kernels],
-    'sum_avg_us': sum(s['avg_us'] for s in iter_kernels),
-    'hbm_bytes': sum(pmc.get(s['kernel'], {}).get('hbm_bytes_per_launch', 0) for s in iter_kernels),
+    # launches of each loop kernel per batched iteration (2 for the sequential schedule; 4 mixed
+    # launches with two queues, which overlap pairwise)
+    'launches_per_iteration': {s['kernel']: round(s['calls'] / steps, 2) for s in iter_kernels},
+    'sum_kernel_time_us': sum(s['avg_us'] * s['calls'] / steps for s in iter_kernels),
+    'wall_us_per_iteration_hip_events': (bench or {}).get('hip_event_ms_per_step', 0) * 1e3,
+    'hbm_bytes': sum(pmc.get(s['kernel'], {}).get('hbm_bytes_per_launch', 0) * s['calls'] / steps for s in iter_kernels),
     'algorithmic_bytes_57N': 57 * 65536 * 512,
 }
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'rocprof_%s.json' % tag), 'w'), indent=1)
@@ -77,6 +83,8 @@ for s in stats:
         s['kernel'], s['calls'], s['avg_us'], d.get('hbm_bytes_per_launch', 0) / 1e6,
         d.get('hbm_bytes_per_launch', 0) / (s['avg_us'] * 1e-6) / 1e12 if s['avg_us'] else 0))
 # bench.py reads this for roofline.traffic
+if not update_traffic:
+    sys.exit(0)
 tj = os.path.join(ROOT, 'profiles', 'traffic.json')
 cur = json.load(open(tj)) if os.path.exists(tj) else {}
 path = bench['config']['path'] if bench else 'fused'

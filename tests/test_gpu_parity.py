@@ -511,3 +511,31 @@ def test_prox_edge_values(P, torch):
         P.utils_pnp.prox_cnc(eng, tx, tz, tw, 0.45, 0.5, 0.05, 64)
         zr, wr = O.cnc_step(x.astype(np.float64), z.astype(np.float64), w.astype(np.float64), 0.45, 0.5, 0.05, 64)
         assert np.abs(tz.cpu().numpy() - zr).max() <= 1e-6 and np.abs(tw.cpu().numpy() - wr).max() <= 1e-6
+
+
+def test_schedules_are_bit_identical(P):
+    """The batch may be split over HIP queues (PNP_FUSED_STREAMS) and row/column workgroups of
+    different halves may share one launch (PNP_FUSED_SCHED=1): scheduling only -- every slice
+    sees the same arithmetic, so all schedules give the same bits."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import pnp_admm_cnc_mri_amd as P\n"
+        "from pnp_admm_cnc_mri_amd import synthetic as S\n"
+        "m = S.reference_masks(); masks = np.stack([m['Q_Random30'], m['Q_Cartesian30']]).astype(np.uint8)\n"
+        "B = 131; img, noise = S.batch(0, B)\n"
+        "eng = P.Engine(256, 256, Bmax=B); eng.synthesize(img, noise, masks, np.arange(B) %% 2); eng.init_state()\n"
+        "eng.admm_cnc(6, 0.45, 0.5, 0.05, 64); x = eng.x(); z, w = eng.get_state()\n"
+        "eng.init_state(); eng.admm_l1(5, 0.1, 0.015); xl = eng.x()\n"
+        "np.savez(sys.argv[1], x=x, z=z, w=w, xl=xl)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for sched, streams, chunk in (('0', '1', '0'), ('1', '1', '0'), ('0', '2', '0'), ('1', '2', '0'), ('0', '3', '0'), ('0', '1', '48')):
+        path = '/tmp/sched_%s_%s_%s.npz' % (sched, streams, chunk)
+        subprocess.check_call([sys.executable, '-c', code, path],
+                              env=dict(os.environ, PNP_FUSED_SCHED=sched, PNP_FUSED_STREAMS=streams, PNP_FUSED_CHUNK=chunk))
+        outs.append(np.load(path))
+    for o in outs[1:]:
+        for k in ('x', 'z', 'w', 'xl'):
+            assert np.array_equal(outs[0][k], o[k]), k
