@@ -183,8 +183,10 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'note': 'achieved = 57*H*W*B algorithmic bytes per iteration / HIP-event time per iteration '
-                                 '(all launches of one iteration; with 2 queues they overlap pairwise, so rocprof kernel '
-                                 'durations sum to ~2x this time); traffic = PMC-measured HBM bytes per iteration'},
+                                 '(all launches of one iteration: 4 k_fmixed launches over 2 HIP queues whose heads and '
+                                 'tails overlap, so rocprof per-launch durations sum to ~1.1x this time; PNP_FUSED_STREAMS=1 '
+                                 'PNP_FUSED_SCHED=0 gives the sequential 2-kernel schedule, profiles/rocprof_*_sequential.json); '
+                                 'traffic = PMC-measured HBM bytes per iteration'},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)
