@@ -65,6 +65,8 @@ def main():
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='slices per GPU (default 512 = the headline config)')
     ap.add_argument('--solver', choices=['cnc', 'l1'], default='cnc')
     ap.add_argument('--generic', action='store_true', help='force the generic (unfused) kernels')
+    ap.add_argument('--size', type=int, default=256, choices=[256, 512],
+                    help='slice edge; 512 = the shape of config 5 (seeded masks, mask_id = b %% 3), not the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--rehearse-gloo', action='store_true',
@@ -96,10 +98,16 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     B = args.batch
-    mk = S.reference_masks()
-    masks = np.stack([mk['Q_Random30']]).astype(np.uint8)            # config 2: Q_Random30 for every slice
-    mask_id = np.zeros(B, np.int32)
-    img, noise = S.batch(rank * B, B)                                 # this rank's shard of the job
+    global H, W
+    H = W = args.size
+    if args.size == 256:
+        mk = S.reference_masks()
+        masks = np.stack([mk['Q_Random30']]).astype(np.uint8)        # config 2: Q_Random30 for every slice
+        mask_id = np.zeros(B, np.int32)
+    else:
+        masks = np.stack([S.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+        mask_id = (np.arange(B) % 3).astype(np.int32)
+    img, noise = S.batch(rank * B, B, H, W)                           # this rank's shard of the job
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)
     if args.generic:
@@ -172,8 +180,8 @@ def main():
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'ADMM_%s, %d synthetic 256x256 complex64 slices per GPU, Q_Random30, S4:176 presets'
-                                   % (args.solver.upper(), B),
+            'config': {'workload': 'ADMM_%s, %d synthetic %dx%d complex64 slices per GPU, %s, S4:176 presets'
+                                   % (args.solver.upper(), B, H, W, 'Q_Random30' if H == 256 else 'seeded mask bank of 3'),
                        'slices_per_gpu': B, 'path': eng.path_name,
                        'queues': int(os.environ.get('PNP_FUSED_STREAMS', '2')) if eng.path_name == 'fused' else 1,
                        'mixed_row_col_launches': (os.environ.get('PNP_FUSED_SCHED', '1') == '1') if eng.path_name == 'fused' else False},

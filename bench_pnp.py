@@ -26,8 +26,10 @@ def main():
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
     ap.add_argument('--channels-last', action='store_true')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
     args = ap.parse_args()
     fam = D.family(args.model)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     mname = args.mask or {'ffdnet': 'Q_Radial30', 'drunet': 'Q_Cartesian30'}.get(fam, 'Q_Random30')
     mask = S.reference_masks()[mname].astype(np.uint8)
     B = args.batch

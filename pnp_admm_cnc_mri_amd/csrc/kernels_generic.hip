@@ -280,12 +280,14 @@ static hipError_t launch_cols_t(hipStream_t s, int W, const ColArgsT<R>& a) {
     using C = typename CxOf<R>::type;
     constexpr int COLS = ColCfg<N, R>::COLS;
     const size_t lds = sizeof(C) * (2 * COLS * (N + 1) + N);
-    static bool attr_done = false;          // >64 KiB dynamic LDS needs the opt-in once per kernel
-    if (!attr_done) {
+    static bool attr_done[64] = {};         // >64 KiB dynamic LDS needs the opt-in once per kernel and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)k_cols<N, PRE, MID, POST, R>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL((k_cols<N, PRE, MID, POST, R>), dim3(a.B * (W / COLS)), dim3(256), lds, s, a, W);
     return hipGetLastError();

@@ -137,3 +137,34 @@ def test_glue_kernels(env):
         eng.dual_clamp(x2, z2, w2)
         wr = (w + x - z)
         assert torch.equal(x2, x.clamp(0, 1)) and torch.equal(z2, z.clamp(0, 1)) and torch.equal(w2, wr.clamp(0, 1))
+
+
+def test_config5_shape_512_mixed_masks_drunet(env, tmp_path):
+    """config 5's shape: PNP_ADMM_CNC_D at 512x512 with a bank of three masks (mask_id = b % 3) and
+    DRUNet going through the four-quadrant split of test_mode(mode=2) (utils/utils_model.py:91-108).
+    Checked against the oracle loop driven with the same GPU denoiser."""
+    torch, D = env['torch'], env['D']
+    H = W = 512
+    masks = np.stack([O.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+    B = 3
+    mid = np.arange(B, dtype=np.int32) % 3
+    ys = np.stack([O.synthetic_problem(b, masks[mid[b]], H, W)[1] for b in range(B)]).astype(np.complex64)
+    name = 'drunet_gray'
+    net, nlm, _ = D.build(name)
+    sd = D.seeded_state_dict(net, 5)
+    net.load_state_dict(sd)
+    iters = 2
+    from pnp_admm_cnc_mri_amd import utils_pnp
+    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig).to(torch.device('cuda'))
+
+    def denoise(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return den(t, i)[0, 0].cpu().numpy()
+
+    opts = dict(alpha=1, iter_num=iters, lambda1=0.8, reo=0.8, b=0.45)           # S6:577 preset, 2 iterations
+    out, _ = env['S'].PNP_ADMM_CNC_D(name, masks, None, y=ys, mask_id=mid, model=sd, results=str(tmp_path), **opts)
+    for b in range(B):
+        ref = O.pnp_admm_cnc(ys[b].astype(np.complex128), masks[mid[b]], denoise, iters, 1, 0.8, 0.8, 0.45)
+        assert out[b].shape == (H, W)
+        assert rel_l2(out[b], ref) <= 2e-5, (b, rel_l2(out[b], ref))
