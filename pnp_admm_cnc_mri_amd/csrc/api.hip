@@ -47,7 +47,8 @@ struct pnp_ctx {
     void* stage = nullptr;            // staging for host inputs of synthesize
     size_t stage_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    Fused256* fused = nullptr;
+    Fused256* fused = nullptr;        // 256 x 256
+    Fused512* fused5 = nullptr;       // 512 x 512
     bool fused_ready = false;         // tables prepared for the current problem
     // fp64 validation context (pnp_ctx_create_f64): same loop, generic kernels, double buffers
     bool f64 = false;
@@ -74,7 +75,7 @@ static ProxParams make_prox_cnc(double alpha, double lambda1, double reo, double
 }
 static float dc_coeff(double reo) { return (float)(1.0 / (1.0 + 1.0 / 2.0 / reo)); }
 
-static bool use_fused(pnp_ctx* c) { return c->fast && c->fused && c->fused_ready; }
+static bool use_fused(pnp_ctx* c) { return c->fast && (c->fused || c->fused5) && c->fused_ready; }
 
 extern "C" {
 
@@ -124,10 +125,11 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
         pnp_ctx_destroy(c);
         return fail(e == hipErrorOutOfMemory ? PNP_E_NOMEM : PNP_E_HIP, "pnp_ctx_create: %s", hipGetErrorString(e));
     }
-    if (!f64 && H == 256 && W == 256) {
+    if (!f64 && H == W) {
         hipError_t fe = hipSuccess;
-        c->fused = fused256_create(Bmax, &fe);      // null when the fused path is unavailable
-        if (!c->fused && fe != hipSuccess && fe != hipErrorNotSupported) {
+        if (H == 256) c->fused = fused256_create(Bmax, &fe);
+        else          c->fused5 = fused512_create(Bmax, &fe);
+        if (!c->fused && !c->fused5) {
             pnp_ctx_destroy(c);
             return fail(PNP_E_HIP, "pnp_ctx_create: fused path: %s", hipGetErrorString(fe));
         }
@@ -143,6 +145,7 @@ int pnp_ctx_destroy(pnp_ctx* c) {
     if (!c) return PNP_OK;
     (void)hipSetDevice(c->device);
     if (c->fused) fused256_destroy(c->fused);
+    if (c->fused5) fused512_destroy(c->fused5);
     void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage,
                     c->yd, c->workd, c->zd, c->wd, c->xd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -197,6 +200,9 @@ static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_i
 static int prepare_fused(pnp_ctx* c) {
     if (c->fused) {
         HIPCHK(fused256_prepare(c->fused, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
+        c->fused_ready = true;
+    } else if (c->fused5) {
+        HIPCHK(fused512_prepare(c->fused5, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
         c->fused_ready = true;
     }
     return PNP_OK;
@@ -335,7 +341,8 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, doubl
     if (iters == 0) return PNP_OK;
     const float cdc = dc_coeff(reo);
     if (use_fused(c)) {
-        HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp));
+        if (c->fused) HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp));
+        else          HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp));
     } else {
         for (int i = 0; i < iters; ++i) {
             int rc = generic_iteration(c, c->z, c->w, cnc ? EPI_CNC : EPI_L1, pp, cdc,
@@ -381,7 +388,8 @@ int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo
     if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
     if (use_fused(c)) {
-        HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        if (c->fused) HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        else          HIPCHK(fused512_dc(c->fused5, c->stream, z, w, x, c->B, dc_coeff(reo)));
         return PNP_OK;
     }
     return generic_iteration(c, z, w, EPI_ABS_REAL, ProxParams{}, dc_coeff(reo), x, nullptr, nullptr);

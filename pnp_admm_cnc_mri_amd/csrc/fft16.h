@@ -91,6 +91,44 @@ template <bool INV>
 PNP_HD void fft256_tail(c32 (&a)[16]) { dft16<INV>(a); }
 
 // ----------------------------------------------------------------------------------------------
+// 512 = 16 points x 32 lanes.  Two lane layouts:
+//   t-layout : lane t (0..31), register j  <->  index t + 32 j
+//   k-layout : lane L = 2 k2 + h (k2 0..15, h 0..1), register q  <->  index k2 + 16 q + 256 h
+// "A" structure (t-layout in, k-layout out):  dft16 -> W512^(t k2) -> exchange -> dft16 -> W32^(q h)
+//                                              -> radix-2 butterfly between lanes L and L^1
+// "B" structure (k-layout in, t-layout out) is its transposed flow graph (the DFT matrix is
+// symmetric):  butterfly -> W32^(q h) -> dft16 -> exchange -> W512^(t k2) -> dft16.
+// INV conjugates every twiddle, i.e. selects the direction of the transform; both structures
+// serve both directions.  tw = W512 table (forward values), tw[16 q h] = W32^(q h).
+// ----------------------------------------------------------------------------------------------
+template <bool INV>
+PNP_HD void fft512_a1(c32 (&a)[16], const c32* tw, int t) {            // before the exchange
+    dft16<INV>(a);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[t * k]);
+}
+template <bool INV>
+PNP_HD void fft512_a2(c32 (&a)[16], const c32* tw, int h) {            // after it, before the butterfly
+    dft16<INV>(a);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) a[q] = tmul<INV>(a[q], tw[16 * q * h]);
+}
+// butterfly of lanes (k2,0),(k2,1): the h = 0 lane keeps the sum, the h = 1 lane the difference
+PNP_HD c32 bfly2(c32 own, c32 other, int h) { return h ? (other - own) : (own + other); }
+template <bool INV>
+PNP_HD void fft512_b1(c32 (&a)[16], const c32* tw, int h) {            // after the butterfly, before the exchange
+#pragma unroll
+    for (int q = 1; q < 16; ++q) a[q] = tmul<INV>(a[q], tw[16 * q * h]);
+    dft16<INV>(a);
+}
+template <bool INV>
+PNP_HD void fft512_b2(c32 (&a)[16], const c32* tw, int t) {            // after the exchange
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[t * k]);
+    dft16<INV>(a);
+}
+
+// ----------------------------------------------------------------------------------------------
 // z / w updates shared by all kernels (S1:123-126, S4:127-132)
 // ----------------------------------------------------------------------------------------------
 struct ProxCoef {

@@ -48,4 +48,38 @@ PNP_HD void hermitian_entry(const c32* y, const uint8_t* mask, int k1, int k2, c
     code = m1 + m2;
 }
 
+// ----------------------------------------------------------------------------------------------
+// 512 x 512: same scheme, 32 lanes per transform (fft16.h, "512 = 16 points x 32 lanes").
+//   T  : [pair][r][phi512(k2)] c32, 2 MiB per pair; phi512: [0]=col 0, [1]=col 256, [2q]=col q, [2q+1]=col 512-q
+//   Yh : [pair][tile m:33][wave:4][reg q:16][lane:64] float4,  Mh : [pair][tile][wave][lane] u64
+// in the column kernel's thread order: tile m holds column pairs 8m .. 8m+7 (m = 32: column 256),
+// lane = kl + 8 tq, t = 8 wave + tq, and after the forward transform lane t, register q hold
+// k1 = (t >> 1) + 16 q + 256 (t & 1)  (the k-layout of fft16.h).
+// ----------------------------------------------------------------------------------------------
+constexpr int F5_N = 512;
+constexpr int F5_HALF = 257;                 // k2 = 0..256
+constexpr int F5_TILES = 33;
+constexpr size_t YH5_PAIR = (size_t)F5_TILES * 4 * 16 * 64;
+constexpr size_t MH5_PAIR = (size_t)F5_TILES * 4 * 64;
+
+PNP_HD int phi512(int k) { return k < 256 ? 2 * k : (k == 256 ? 1 : 1025 - 2 * k); }
+PNP_HD size_t yh5_index(int pair, int k2, int k1) {
+    const int m = k2 >> 3, kl = k2 & 7;
+    const int t = 2 * (k1 & 15) + (k1 >> 8), q = (k1 >> 4) & 15;
+    const int wv = t >> 3, lane = kl + 8 * (t & 7);
+    return (size_t)pair * YH5_PAIR + (((size_t)(m * 4 + wv) * 16 + q) * 64 + lane);
+}
+PNP_HD size_t mh5_index(int pair, int k2, int t) {
+    const int m = k2 >> 3, kl = k2 & 7, wv = t >> 3, lane = kl + 8 * (t & 7);
+    return (size_t)pair * MH5_PAIR + ((size_t)(m * 4 + wv) * 64 + lane);
+}
+PNP_HD void hermitian_entry512(const c32* y, const uint8_t* mask, int k1, int k2, c32& yh, int& code) {
+    const int i1 = k1 * F5_N + k2;
+    const int i2 = ((F5_N - k1) & 511) * F5_N + ((F5_N - k2) & 511);
+    const int m1 = mask[i1] != 0, m2 = mask[i2] != 0;
+    const c32 y1 = y[i1], y2 = y[i2];
+    yh = mk(0.5f * ((float)m1 * y1.x + (float)m2 * y2.x), 0.5f * ((float)m1 * y1.y - (float)m2 * y2.y));
+    code = m1 + m2;
+}
+
 }  // namespace pnp

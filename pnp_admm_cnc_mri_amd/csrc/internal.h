@@ -84,4 +84,14 @@ hipError_t fused256_run(Fused256*, hipStream_t s, float* z, float* w, float* x, 
 hipError_t fused256_dc(Fused256*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
 int        fused256_kernels_per_iteration();
 
+// fused 512x512 path (kernels_fused512.hip): same scheme with 32-lane transforms
+struct Fused512;
+Fused512*  fused512_create(int Bmax, hipError_t* err);
+void       fused512_destroy(Fused512*);
+hipError_t fused512_prepare(Fused512*, hipStream_t s, const float2* y, const uint8_t* mask_bank,
+                            const int32_t* mask_id, int B);
+hipError_t fused512_run(Fused512*, hipStream_t s, float* z, float* w, float* x, int B, int iters,
+                        bool cnc, float dc_c, ProxParams p);
+hipError_t fused512_dc(Fused512*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
+
 }  // namespace pnp

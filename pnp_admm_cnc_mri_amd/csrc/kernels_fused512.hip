@@ -1,0 +1,477 @@
+// Fused gfx950 kernels for 512x512 slices (the shape of BASELINE.json's config 5): the scheme of
+// kernels_fused256.hip -- two real slices per complex field, Hermitian k-space blend, mirror-column
+// trick, 2 launches per iteration -- with 32-lane cooperative transforms (fft16.h: 512 = 16 points
+// x 32 lanes; structure A: t-layout -> k-layout, structure B: k-layout -> t-layout, each in both
+// directions).  Layouts: fused_layout.h.
+//
+//   k5_rows : 8 rows of a slice pair per 256-thread workgroup (a row = 32 consecutive lanes; the
+//             radix-2 partner is lane^1: one DPP quad_perm move)
+//   k5_cols : 8 column pairs (k2, 512-k2) per workgroup; lane = pair + 8*t_low so that global
+//             accesses are 16-byte {P,Q} elements in 128-byte row segments; the radix-2 partner
+//             is lane^8 (DPP row_ror:8)
+// HBM bytes per slice-iteration: 36 N, as at 256x256.
+#include "internal.h"
+#include "fused_layout.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace pnp {
+
+__device__ c32 g_tw512f[512];
+
+struct Fused512 {
+    int Bmax = 0, np = 0;
+    c32* T = nullptr;
+    float4* Yh = nullptr;
+    unsigned long long* Mh = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+constexpr int NN5 = 512 * 512;
+
+static inline ProxCoef to_coef5(const ProxParams& p) {
+    ProxCoef c;
+    c.thr = p.thr; c.c1 = p.c1; c.c2 = p.c2; c.c3 = p.c3; c.ib = p.ib;
+    return c;
+}
+
+__device__ __forceinline__ float dpp_quad_swap1(float v) {      // lane ^ 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_row_ror8(float v) {        // lane ^ 8 inside a row of 16 lanes
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128 /* row_ror:8 */, 0xF, 0xF, true));
+}
+
+// ------------------------------------------------------------------------------------------
+// table preparation: one block per (column k2 = 0..256, pair)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k5_prepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
+                                                  float4* Yh, unsigned long long* Mh, int B) {
+    __shared__ int nib[512];                         // [t:32][q:16]
+    const int tid = threadIdx.x, k2 = blockIdx.x, pair = blockIdx.y;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int k1 = tid + 256 * rep;
+        c32 yh[2] = {mk(0.f, 0.f), mk(0.f, 0.f)};
+        int code[2] = {0, 0};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sl = 2 * pair + s;
+            if (sl < B) {
+                const int mid = mask_id ? mask_id[sl] : 0;
+                hermitian_entry512(y + (size_t)sl * NN5, mask_bank + (size_t)mid * NN5, k1, k2, yh[s], code[s]);
+            }
+        }
+        Yh[yh5_index(pair, k2, k1)] = make_float4(yh[0].x, yh[0].y, yh[1].x, yh[1].y);
+        const int t = 2 * (k1 & 15) + (k1 >> 8), q = (k1 >> 4) & 15;
+        nib[t * 16 + q] = code[0] | (code[1] << 2);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v |= (unsigned long long)nib[tid * 16 + q] << (4 * q);
+        Mh[mh5_index(pair, k2, tid)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rows
+// ------------------------------------------------------------------------------------------
+struct F5RowArgs {
+    c32* T;
+    const float* z_in;
+    const float* w_in;
+    float* z_out;
+    float* w_out;
+    float* x_out;
+    int B;
+    float scale;
+    ProxCoef prox;
+    int u_first;
+};
+
+constexpr int RP5 = 520;     // LDS pitch (c32) of a staged row
+constexpr int XP5 = 544;     // exchange region per 32-lane group: 16 runs of 34
+constexpr int ROWS5_LDS = 8 * XP5 + 512;
+
+// exchanges between the lanes of one 32-lane group through its LDS region (block barriers: all
+// 8 groups of the workgroup exchange together)
+__device__ __forceinline__ void xchg_t2k(c32 (&a)[16], c32* region, int t) {
+    const int k2 = t >> 1, h = t & 1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) region[k * 34 + t] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = region[k2 * 34 + 2 * i + h];
+    __syncthreads();
+}
+__device__ __forceinline__ void xchg_k2t(c32 (&a)[16], c32* region, int t) {
+    const int k2 = t >> 1, h = t & 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) region[k2 * 34 + 2 * i + h] = a[i];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = region[k * 34 + t];
+    __syncthreads();
+}
+
+// PROX as in kernels_fused256.hip: 0 none, 1 L1 (z and w), 2 CNC, 3 L1 single-state
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__global__ __launch_bounds__(256) void k5_rows(F5RowArgs p) {
+    __shared__ __attribute__((aligned(16))) c32 lds[ROWS5_LDS];
+    const int tid = threadIdx.x, g = tid >> 5, t = tid & 31;
+    const int k2 = t >> 1, h = t & 1;
+    c32* twl = lds + 8 * XP5;
+    twl[tid] = g_tw512f[tid];
+    twl[tid + 256] = g_tw512f[tid + 256];
+    const int pair = blockIdx.x >> 6, r0 = (blockIdx.x & 63) * 8;
+    const int sa = 2 * pair, sb = sa + 1;
+    const bool has_b = sb < p.B;
+    c32 a[16];
+    c32* Tt = p.T + (size_t)pair * NN5 + (size_t)r0 * 512;       // this block's 8 rows, contiguous
+    c32* region = lds + g * XP5;
+
+    if (HAS_INV) {
+        const float4* src = reinterpret_cast<const float4*>(Tt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 8, c2 = idx & 255;
+            *reinterpret_cast<float4*>(&lds[row * RP5 + 2 * c2]) = src[idx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = lds[g * RP5 + phi512(k2 + 16 * q + 256 * h)];
+        __syncthreads();
+        // structure B, inverse direction: k-layout -> t-layout
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_quad_swap1(a[q].x), dpp_quad_swap1(a[q].y)), h);
+        fft512_b1<true>(a, twl, h);
+        xchg_k2t(a, region, t);
+        fft512_b2<true>(a, twl, t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[g * RP5 + t + 32 * j] = a[j];
+        __syncthreads();
+    } else {
+        __syncthreads();                                         // twiddle table visible
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 7, n4 = (idx & 127) * 4;
+        const size_t off = (size_t)(r0 + row) * 512 + n4;
+        float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
+        if (HAS_INV) {
+            const float4 c01 = *reinterpret_cast<const float4*>(&lds[row * RP5 + n4]);
+            const float4 c23 = *reinterpret_cast<const float4*>(&lds[row * RP5 + n4 + 2]);
+            xa[0] = fabsf(c01.x) * p.scale; xb[0] = fabsf(c01.y) * p.scale;
+            xa[1] = fabsf(c01.z) * p.scale; xb[1] = fabsf(c01.w) * p.scale;
+            xa[2] = fabsf(c23.x) * p.scale; xb[2] = fabsf(c23.y) * p.scale;
+            xa[3] = fabsf(c23.z) * p.scale; xb[3] = fabsf(c23.w) * p.scale;
+        }
+        float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+        if (PROX == 3) {
+            const float4 q1 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * NN5 + off);
+            wa[0] = q1.x; wa[1] = q1.y; wa[2] = q1.z; wa[3] = q1.w;
+            if (has_b) {
+                const float4 q2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * NN5 + off);
+                wb[0] = q2.x; wb[1] = q2.y; wb[2] = q2.z; wb[3] = q2.w;
+            }
+            float ua[4], ub[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!p.u_first) {
+                    wa[q] = wa[q] - soft_thr(wa[q], p.prox.thr);
+                    wb[q] = wb[q] - soft_thr(wb[q], p.prox.thr);
+                }
+                ua[q] = xa[q] + wa[q];
+                ub[q] = xb[q] + wb[q];
+                za[q] = soft_thr(ua[q], p.prox.thr); wa[q] = ua[q] - za[q];
+                zb[q] = soft_thr(ub[q], p.prox.thr); wb[q] = ub[q] - zb[q];
+            }
+            if (HAS_FWD) {
+                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * NN5 + off) = make_float4(ua[0], ua[1], ua[2], ua[3]);
+                if (has_b) *reinterpret_cast<float4*>(p.w_out + (size_t)sb * NN5 + off) = make_float4(ub[0], ub[1], ub[2], ub[3]);
+            } else {
+                *reinterpret_cast<float4*>(p.z_out + (size_t)sa * NN5 + off) = make_float4(za[0], za[1], za[2], za[3]);
+                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * NN5 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
+                if (has_b) {
+                    *reinterpret_cast<float4*>(p.z_out + (size_t)sb * NN5 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
+                    *reinterpret_cast<float4*>(p.w_out + (size_t)sb * NN5 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
+                }
+            }
+        }
+        if ((PROX != 0 && PROX != 3) || !HAS_INV) {
+            const float4 v1 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sa * NN5 + off);
+            const float4 v2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * NN5 + off);
+            za[0] = v1.x; za[1] = v1.y; za[2] = v1.z; za[3] = v1.w;
+            wa[0] = v2.x; wa[1] = v2.y; wa[2] = v2.z; wa[3] = v2.w;
+            if (has_b) {
+                const float4 v3 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sb * NN5 + off);
+                const float4 v4 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * NN5 + off);
+                zb[0] = v3.x; zb[1] = v3.y; zb[2] = v3.z; zb[3] = v3.w;
+                wb[0] = v4.x; wb[1] = v4.y; wb[2] = v4.z; wb[3] = v4.w;
+            }
+        }
+        if (PROX == 1 || PROX == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], p.prox); prox_l1_pt(xb[q], zb[q], wb[q], p.prox); }
+                else           { prox_cnc_pt(xa[q], za[q], wa[q], p.prox); prox_cnc_pt(xb[q], zb[q], wb[q], p.prox); }
+            }
+            *reinterpret_cast<float4*>(p.z_out + (size_t)sa * NN5 + off) = make_float4(za[0], za[1], za[2], za[3]);
+            *reinterpret_cast<float4*>(p.w_out + (size_t)sa * NN5 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
+            if (has_b) {
+                *reinterpret_cast<float4*>(p.z_out + (size_t)sb * NN5 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
+                *reinterpret_cast<float4*>(p.w_out + (size_t)sb * NN5 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
+            }
+        }
+        if (WRITE_X) {
+            *reinterpret_cast<float4*>(p.x_out + (size_t)sa * NN5 + off) = make_float4(xa[0], xa[1], xa[2], xa[3]);
+            if (has_b) *reinterpret_cast<float4*>(p.x_out + (size_t)sb * NN5 + off) = make_float4(xb[0], xb[1], xb[2], xb[3]);
+        }
+        if (HAS_FWD) {
+            *reinterpret_cast<float4*>(&lds[row * RP5 + n4]) = make_float4(za[0] - wa[0], zb[0] - wb[0], za[1] - wa[1], zb[1] - wb[1]);
+            *reinterpret_cast<float4*>(&lds[row * RP5 + n4 + 2]) = make_float4(za[2] - wa[2], zb[2] - wb[2], za[3] - wa[3], zb[3] - wb[3]);
+        }
+    }
+
+    if (HAS_FWD) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = lds[g * RP5 + t + 32 * j];
+        __syncthreads();
+        // structure A, forward direction: t-layout -> k-layout
+        fft512_a1<false>(a, twl, t);
+        xchg_t2k(a, region, t);
+        fft512_a2<false>(a, twl, h);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_quad_swap1(a[q].x), dpp_quad_swap1(a[q].y)), h);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lds[g * RP5 + phi512(k2 + 16 * q + 256 * h)] = a[q];
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(Tt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 8, c2 = idx & 255;
+            dst[idx] = *reinterpret_cast<const float4*>(&lds[row * RP5 + 2 * c2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// columns
+// ------------------------------------------------------------------------------------------
+struct F5ColArgs {
+    c32* T;
+    const float4* Yh;
+    const unsigned long long* Mh;
+    float c;
+};
+
+constexpr int CP5 = 548;     // exchange region (c32) per column group
+constexpr int COLS5_LDS = 8 * CP5 + 512;
+
+template <bool INV>
+__device__ __forceinline__ void col5_a(c32 (&a)[16], const c32* twl, c32* region, int t) {     // t-layout -> k-layout
+    const int h = t & 1;
+    fft512_a1<INV>(a, twl, t);
+    xchg_t2k(a, region, t);
+    fft512_a2<INV>(a, twl, h);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_row_ror8(a[q].x), dpp_row_ror8(a[q].y)), h);
+}
+template <bool INV>
+__device__ __forceinline__ void col5_b(c32 (&a)[16], const c32* twl, c32* region, int t) {     // k-layout -> t-layout
+    const int h = t & 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_row_ror8(a[q].x), dpp_row_ror8(a[q].y)), h);
+    fft512_b1<INV>(a, twl, h);
+    xchg_k2t(a, region, t);
+    fft512_b2<INV>(a, twl, t);
+}
+
+__global__ __launch_bounds__(256) void k5_cols(F5ColArgs p) {
+    __shared__ __attribute__((aligned(16))) c32 lds[COLS5_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kl = lane & 7, tq = lane >> 3, t = 8 * wv + tq;       // lanes t and t^1 sit 8 apart in one DPP row
+    c32* twl = lds + 8 * CP5;
+    twl[tid] = g_tw512f[tid];
+    twl[tid + 256] = g_tw512f[tid + 256];
+    const int pair = blockIdx.x / 33, m = blockIdx.x % 33;
+    // tiles 0..31: column pairs q = 8 m + kl (q >= 1) = physical columns (2q, 2q+1);
+    // tile 32: the two self-mirrored columns 0 and 256 (physical 0 and 1), one lane group each.
+    const bool self = (m == 32);
+    const int k2 = self ? (kl == 0 ? 0 : 256) : 8 * m + kl;
+    const bool valid = self ? (kl < 2) : (k2 >= 1);
+    c32* Tp = p.T + (size_t)pair * NN5;
+    c32 P[16], Q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        P[j] = mk(0.f, 0.f);
+        Q[j] = mk(0.f, 0.f);
+        if (valid) {
+            const c32* rowp = Tp + (size_t)(t + 32 * j) * 512;
+            if (self) {
+                P[j] = rowp[kl];
+                Q[j] = P[j];
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(rowp + 2 * k2);
+                P[j] = mk(v.x, v.y);
+                Q[j] = mk(v.z, v.w);
+            }
+        }
+    }
+    c32* region = lds + kl * CP5;
+    __syncthreads();                             // twiddle table visible
+    col5_a<false>(P, twl, region, t);            // P[q] = C[k1, k2],   k1 = (t>>1) + 16 q + 256 (t&1)
+    col5_a<true>(Q, twl, region, t);             // Q[q] = C[-k1, -k2]
+    if (valid) {
+        const int m_tab = k2 >> 3, kl_tab = k2 & 7;
+        const unsigned long long code = p.Mh[(size_t)pair * MH5_PAIR + ((size_t)(m_tab * 4 + wv) * 64 + kl_tab + 8 * tq)];
+        const float4* yhp = p.Yh + (size_t)pair * YH5_PAIR + ((size_t)(m_tab * 4 + wv) * 16) * 64 + kl_tab + 8 * tq;
+        const float ch = 0.5f * p.c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 yh = yhp[q * 64];
+            const int nibv = (int)((code >> (4 * q)) & 15ull);
+            blend_pair(P[q], Q[q], mk(yh.x, yh.y), mk(yh.z, yh.w), nibv & 3, nibv >> 2, p.c, ch);
+        }
+    }
+    col5_b<true>(P, twl, region, t);             // column k2 of the blended field
+    col5_b<false>(Q, twl, region, t);            // column 512 - k2
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            c32* rowp = Tp + (size_t)(t + 32 * j) * 512;
+            if (self) rowp[kl] = P[j];
+            else *reinterpret_cast<float4*>(rowp + 2 * k2) = make_float4(P[j].x, P[j].y, Q[j].x, Q[j].y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+Fused512* fused512_create(int Bmax, hipError_t* err) {
+    Fused512* f = new Fused512();
+    f->Bmax = Bmax;
+    f->np = (Bmax + 1) / 2;
+    hipError_t e = hipMalloc((void**)&f->T, (size_t)f->np * NN5 * sizeof(c32));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Yh, (size_t)f->np * YH5_PAIR * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)f->np * MH5_PAIR * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        static thread_local c32 h[512];
+        for (int m = 0; m < 512; ++m) {
+            const double a = -2.0 * M_PI * (double)m / 512.0;
+            h[m] = mk((float)cos(a), (float)sin(a));
+        }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw512f), h, sizeof(h));
+    }
+    if (e != hipSuccess) {
+        fused512_destroy(f);
+        *err = e;
+        return nullptr;
+    }
+    *err = hipSuccess;
+    return f;
+}
+
+void fused512_destroy(Fused512* f) {
+    if (!f) return;
+    if (f->T) (void)hipFree(f->T);
+    if (f->Yh) (void)hipFree(f->Yh);
+    if (f->Mh) (void)hipFree(f->Mh);
+    if (f->side) (void)hipStreamDestroy(f->side);
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
+    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+    delete f;
+}
+
+hipError_t fused512_prepare(Fused512* f, hipStream_t s, const float2* y, const uint8_t* mask_bank,
+                            const int32_t* mask_id, int B) {
+    if (B > f->Bmax) return hipErrorInvalidValue;
+    const int np = (B + 1) / 2;
+    hipLaunchKernelGGL(k5_prepare, dim3(F5_HALF, np), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank,
+                       mask_id, f->Yh, f->Mh, B);
+    return hipGetLastError();
+}
+
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+static hipError_t launch5_rows(hipStream_t s, int np, const F5RowArgs& a) {
+    hipLaunchKernelGGL((k5_rows<HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 64), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch5_cols(Fused512* f, hipStream_t s, int pair0, int np, float c) {
+    F5ColArgs a;
+    a.T = f->T + (size_t)pair0 * NN5;
+    a.Yh = f->Yh + (size_t)pair0 * YH5_PAIR;
+    a.Mh = f->Mh + (size_t)pair0 * MH5_PAIR;
+    a.c = c;
+    hipLaunchKernelGGL(k5_cols, dim3(np * 33), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+static hipError_t run5_chunk(Fused512* f, hipStream_t s, float* z, float* w, float* x, int c0, int Bc, int iters,
+                             int prox, float dc_c, const ProxParams& pp) {
+    const int np = (Bc + 1) / 2, pair0 = c0 / 2;
+    const size_t so = (size_t)c0 * NN5;
+    F5RowArgs a;
+    a.T = f->T + (size_t)pair0 * NN5;
+    a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
+    a.scale = 1.0f / (float)NN5; a.prox = to_coef5(pp); a.u_first = 1;
+    hipError_t e = launch5_rows<false, 0, true, false>(s, np, a);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) {
+        e = launch5_cols(f, s, pair0, np, dc_c);
+        if (e != hipSuccess) break;
+        const bool last = (i == iters - 1);
+        a.u_first = (i == 0);
+        if (prox == 2)      e = last ? launch5_rows<true, 2, false, true>(s, np, a) : launch5_rows<true, 2, true, false>(s, np, a);
+        else if (prox == 1) e = last ? launch5_rows<true, 1, false, true>(s, np, a) : launch5_rows<true, 1, true, false>(s, np, a);
+        else                e = last ? launch5_rows<true, 3, false, true>(s, np, a) : launch5_rows<true, 3, true, false>(s, np, a);
+    }
+    return e;
+}
+
+hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
+                        float dc_c, ProxParams pp) {
+    if (iters <= 0) return hipSuccess;
+    static int streams = -1, two_state = -1;
+    if (streams < 0) { const char* e = getenv("PNP_FUSED_STREAMS"); streams = e ? atoi(e) : 2; }
+    if (two_state < 0) { const char* e = getenv("PNP_FUSED_L1_TWO_STATE"); two_state = e ? atoi(e) : 0; }
+    const int prox = cnc ? 2 : (two_state ? 1 : 3);
+    if (streams >= 2 && B >= 32) {
+        // two halves of the batch on two queues (see kernels_fused256.hip): kernel heads and tails overlap
+        hipError_t e = hipSuccess;
+        if (!f->side) {
+            e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        const int B1 = ((B / 2) + 1) & ~1;
+        e = hipEventRecord(f->ev_fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(f->side, f->ev_fork, 0);
+        if (e == hipSuccess) e = run5_chunk(f, s, z, w, x, 0, B1, iters, prox, dc_c, pp);
+        if (e == hipSuccess) e = run5_chunk(f, f->side, z, w, x, B1, B - B1, iters, prox, dc_c, pp);
+        if (e == hipSuccess) e = hipEventRecord(f->ev_join, f->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join, 0);
+        return e;
+    }
+    return run5_chunk(f, s, z, w, x, 0, B, iters, prox, dc_c, pp);
+}
+
+hipError_t fused512_dc(Fused512* f, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c) {
+    const int np = (B + 1) / 2;
+    F5RowArgs a;
+    a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = nullptr; a.w_out = nullptr; a.x_out = x; a.B = B;
+    a.scale = 1.0f / (float)NN5; a.prox = ProxCoef{}; a.u_first = 1;
+    hipError_t e = launch5_rows<false, 0, true, false>(s, np, a);
+    if (e == hipSuccess) e = launch5_cols(f, s, 0, np, dc_c);
+    if (e == hipSuccess) e = launch5_rows<true, 0, false, true>(s, np, a);
+    return e;
+}
+
+}  // namespace pnp

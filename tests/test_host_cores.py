@@ -75,3 +75,13 @@ def test_fused_pipeline_matches_oracle(emu, golden_inputs, cnc):
         assert rel_l2(raw[0, s], xr) <= 2e-6
         assert rel_l2(raw[1, s], zr) <= 2e-6
         assert np.abs(raw[2, s] - wr).max() <= 2e-6
+
+
+def test_cooperative_fft512_structures(tmp_path):
+    """32-lane 512-point transform of csrc/fft16.h: structure A (t-layout -> k-layout) and its
+    transposed flow graph B, both directions, against a naive double DFT (program exits 0 when
+    every relative error is < 1e-6)."""
+    exe = str(tmp_path / 'fft512_emu')
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'host', 'fft512_emulation.cpp')])
+    out = subprocess.check_output([exe]).decode()
+    assert out.count('rel err') == 4
