@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   3
+#define PNP_ABI_VERSION   4
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -56,6 +56,13 @@ int pnp_set_stream(pnp_ctx* ctx, void* hip_stream);
 int pnp_sync(pnp_ctx* ctx);
 /* 0 = generic kernels only, 1 = allow the fused gfx950 kernels where shapes permit (default). */
 int pnp_set_fast_path(pnp_ctx* ctx, int enable);
+/* Scheduling of the fused loops (results are bit-identical for every setting):
+ *   queues          1..4 HIP queues the batch is split over (default 2; forked/joined on the ctx stream)
+ *   mixed_launches  256x256: row workgroups of one half of a part share each launch with the column
+ *                   workgroups of its other half (default 1)
+ *   chunk           >0: run all iterations on `chunk` slices before the next chunk, one queue (default 0)
+ * Environment defaults read at pnp_ctx_create: PNP_FUSED_STREAMS, PNP_FUSED_SCHED, PNP_FUSED_CHUNK. */
+int pnp_set_schedule(pnp_ctx* ctx, int queues, int mixed_launches, int chunk);
 
 /* ---- problem upload ---------------------------------------------------------------------- */
 /* y: [B][H][W] complex64, the measurements  y = fft2(img)*mask + noises  (S4:102).

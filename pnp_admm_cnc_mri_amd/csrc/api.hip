@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -49,6 +50,7 @@ struct pnp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Fused256* fused = nullptr;        // 256 x 256
     Fused512* fused5 = nullptr;       // 512 x 512
+    FusedSchedule sched;              // defaults overridable by PNP_FUSED_* (read at creation) / pnp_set_schedule
     bool fused_ready = false;         // tables prepared for the current problem
     // fp64 validation context (pnp_ctx_create_f64): same loop, generic kernels, double buffers
     bool f64 = false;
@@ -100,6 +102,11 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
     pnp_ctx* c = new (std::nothrow) pnp_ctx();
     if (!c) return fail(PNP_E_NOMEM, "pnp_ctx_create: host allocation failed");
     c->device = device; c->H = H; c->W = W; c->Bmax = Bmax; c->N = (size_t)H * W; c->f64 = f64;
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    c->sched.queues = env_int("PNP_FUSED_STREAMS", c->sched.queues);
+    c->sched.mixed = env_int("PNP_FUSED_SCHED", c->sched.mixed);
+    c->sched.chunk = env_int("PNP_FUSED_CHUNK", c->sched.chunk);
+    c->sched.l1_two_state = env_int("PNP_FUSED_L1_TWO_STATE", c->sched.l1_two_state);
     const size_t BN = (size_t)Bmax * c->N;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
@@ -163,6 +170,12 @@ int pnp_ctx_destroy(pnp_ctx* c) {
 int pnp_set_stream(pnp_ctx* c, void* s) { CTX(c); c->stream = (hipStream_t)s; return PNP_OK; }
 int pnp_sync(pnp_ctx* c) { CTX(c); HIPCHK(hipStreamSynchronize(c->stream)); return PNP_OK; }
 int pnp_set_fast_path(pnp_ctx* c, int enable) { CTX(c); c->fast = enable != 0; return PNP_OK; }
+int pnp_set_schedule(pnp_ctx* c, int queues, int mixed_launches, int chunk) {
+    CTX(c);
+    if (queues < 1 || queues > 4 || chunk < 0) return fail(PNP_E_ARG, "pnp_set_schedule: queues in 1..4, chunk >= 0");
+    c->sched.queues = queues; c->sched.mixed = mixed_launches != 0; c->sched.chunk = chunk;
+    return PNP_OK;
+}
 
 static int copy_in(pnp_ctx* c, void* dst, const void* src, size_t bytes, int on_device) {
     HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
@@ -341,8 +354,8 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, doubl
     if (iters == 0) return PNP_OK;
     const float cdc = dc_coeff(reo);
     if (use_fused(c)) {
-        if (c->fused) HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp));
-        else          HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp));
+        if (c->fused) HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        else          HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
     } else {
         for (int i = 0; i < iters; ++i) {
             int rc = generic_iteration(c, c->z, c->w, cnc ? EPI_CNC : EPI_L1, pp, cdc,

@@ -69,6 +69,14 @@ hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* o, s
 hipError_t launch_dual_clamp(hipStream_t s, float* x, float* z, float* w, size_t n);
 hipError_t launch_metrics(hipStream_t s, const float* x, const uint8_t* gt, double* acc /*[B][2]*/, int B, int N);
 
+// How the fused loops are scheduled (scheduling only: results are bit-identical for every setting).
+struct FusedSchedule {
+    int queues = 2;         // HIP queues the batch is split over (1..4); kernel heads/tails overlap
+    int mixed = 1;          // 256x256: row workgroups of one half + column workgroups of the other per launch
+    int chunk = 0;          // >0: finish all iterations on `chunk` slices before the next chunk (single queue)
+    int l1_two_state = 0;   // test hook: ADMM_L1 keeps z and w every iteration instead of u only
+};
+
 // fused 256x256 path (kernels_fused256.hip): state resident in the ctx, two slices packed into
 // one complex transform.  See DESIGN.md.
 struct Fused256;
@@ -79,7 +87,7 @@ hipError_t fused256_prepare(Fused256*, hipStream_t s, const float2* y, const uin
                             const int32_t* mask_id, int B);
 // iters iterations of x=dc(z,w); (z,w)=prox(x,z,w) on z,w [B][256][256]; x written on the last
 hipError_t fused256_run(Fused256*, hipStream_t s, float* z, float* w, float* x, int B, int iters,
-                        bool cnc, float dc_c, ProxParams p);
+                        bool cnc, float dc_c, ProxParams p, const FusedSchedule& sch);
 // one data-consistency step on caller pointers
 hipError_t fused256_dc(Fused256*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
 int        fused256_kernels_per_iteration();
@@ -91,7 +99,7 @@ void       fused512_destroy(Fused512*);
 hipError_t fused512_prepare(Fused512*, hipStream_t s, const float2* y, const uint8_t* mask_bank,
                             const int32_t* mask_id, int B);
 hipError_t fused512_run(Fused512*, hipStream_t s, float* z, float* w, float* x, int B, int iters,
-                        bool cnc, float dc_c, ProxParams p);
+                        bool cnc, float dc_c, ProxParams p, const FusedSchedule& sch);
 hipError_t fused512_dc(Fused512*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
 
 }  // namespace pnp

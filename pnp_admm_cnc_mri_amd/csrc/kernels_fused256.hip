@@ -449,49 +449,26 @@ static hipError_t launch_fcols(Fused256* f, hipStream_t s, int pair0, int np, fl
     return hipGetLastError();
 }
 
-// Slices are independent, so a K-iteration run may finish K iterations on one chunk of slices
-// before touching the next: with chunk*(z,w,T,Yh) <= the 256 MiB Infinity Cache the loop's
-// working set stays on die.  0 = no chunking.  (PNP_FUSED_CHUNK overrides, for experiments.)
-static int fused_chunk(int B) {
-    static int env = -1;
-    if (env < 0) {
-        const char* e = getenv("PNP_FUSED_CHUNK");
-        env = e ? atoi(e) : 0;
-        if (env < 0) env = 0;
-    }
-    int c = env > 0 ? env : B;
-    c &= ~1;
-    if (c < 2) c = 2;
-    return c;
-}
-
 // K iterations on slices [c0, c0+Bc) enqueued on stream s
 static hipError_t run_chunk(Fused256* f, hipStream_t s, float* z, float* w, float* x, int c0, int Bc, int iters,
-                            bool cnc, float dc_c, const ProxParams& pp) {
+                            int prox, float dc_c, const ProxParams& pp) {
     const int np = (Bc + 1) / 2, pair0 = c0 / 2;
     const size_t so = (size_t)c0 * 65536;
     FRowArgs a;
     a.T = f->T + (size_t)pair0 * 65536;
     a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
     a.scale = 1.0f / 65536.0f; a.prox = to_coef(pp); a.u_first = 1;
-    static int two_state = -1;              // PNP_FUSED_L1_TWO_STATE=1: test hook, keeps z and w every iteration
-    if (two_state < 0) { const char* ev = getenv("PNP_FUSED_L1_TWO_STATE"); two_state = ev ? atoi(ev) : 0; }
     hipError_t e = launch_frows<false, 0, true, false>(s, np, a);
     for (int i = 0; i < iters && e == hipSuccess; ++i) {
         e = launch_fcols(f, s, pair0, np, dc_c);
         if (e != hipSuccess) break;
         const bool last = (i == iters - 1);
         a.u_first = (i == 0);
-        if (cnc)            e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
-        else if (two_state) e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
+        if (prox == 2)      e = last ? launch_frows<true, 2, false, true>(s, np, a) : launch_frows<true, 2, true, false>(s, np, a);
+        else if (prox == 1) e = last ? launch_frows<true, 1, false, true>(s, np, a) : launch_frows<true, 1, true, false>(s, np, a);
         else                e = last ? launch_frows<true, 3, false, true>(s, np, a) : launch_frows<true, 3, true, false>(s, np, a);
     }
     return e;
-}
-
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
 }
 
 static FRowArgs row_args(Fused256* f, float* z, float* w, float* x, int c0, int Bc, const ProxParams& pp) {
@@ -557,21 +534,20 @@ static hipError_t run_mixed(Fused256* f, hipStream_t s, float* z, float* w, floa
     return e;
 }
 
+// Slices are independent, so the K-iteration chains of different parts of the batch may run on
+// different queues, share launches (run_mixed) or run one chunk after another (chunk*(z,w,T,Yh)
+// <= the 256 MiB Infinity Cache keeps a chunk's working set on die; measured +-2 %).
 hipError_t fused256_run(Fused256* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
-                        float dc_c, ProxParams pp) {
+                        float dc_c, ProxParams pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
-    static int sched = -1, two_state_l1 = -1;
-    if (sched < 0) sched = env_int("PNP_FUSED_SCHED", 1);                // 1 = mixed launches (default), 0 = sequential
-    if (two_state_l1 < 0) two_state_l1 = env_int("PNP_FUSED_L1_TWO_STATE", 0);
-    static int streams = -1;
-    if (streams < 0) streams = env_int("PNP_FUSED_STREAMS", 2);        // HIP queues the batch is split over
-    const int prox = cnc ? 2 : (two_state_l1 ? 1 : 3);
-    if (sched == 1 && B >= 64 && streams < 2) return run_mixed(f, s, z, w, x, 0, B, iters, prox, dc_c, pp);
-    if (streams > Fused256::MAXQ) streams = Fused256::MAXQ;
-    if (streams >= 2 && B >= 32 * streams) {
+    const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
+    int queues = sch.queues < 1 ? 1 : (sch.queues > Fused256::MAXQ ? Fused256::MAXQ : sch.queues);
+    if (sch.chunk > 0) queues = 1;
+    if (queues == 1 && sch.chunk <= 0 && sch.mixed && B >= 64) return run_mixed(f, s, z, w, x, 0, B, iters, prox, dc_c, pp);
+    if (queues >= 2 && B >= 32 * queues) {
         hipError_t e = hipSuccess;
         if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
-        for (int q = 0; q < streams - 1 && e == hipSuccess; ++q) {
+        for (int q = 0; q < queues - 1 && e == hipSuccess; ++q) {
             if (f->side[q]) continue;
             e = hipStreamCreateWithFlags(&f->side[q], hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join[q], hipEventDisableTiming);
@@ -579,22 +555,23 @@ hipError_t fused256_run(Fused256* f, hipStream_t s, float* z, float* w, float* x
         if (e != hipSuccess) return e;
         e = hipEventRecord(f->ev_fork, s);
         int c0 = 0;
-        for (int q = 0; q < streams && e == hipSuccess; ++q) {
-            int Bq = (q == streams - 1) ? (B - c0) : (((B / streams) + 1) & ~1);     // even-sized parts
+        for (int q = 0; q < queues && e == hipSuccess; ++q) {
+            const int Bq = (q == queues - 1) ? (B - c0) : (((B / queues) + 1) & ~1);     // even-sized parts
             hipStream_t sq = (q == 0) ? s : f->side[q - 1];
             if (q > 0) e = hipStreamWaitEvent(sq, f->ev_fork, 0);
-            if (e == hipSuccess) e = (sched == 1 && Bq >= 64) ? run_mixed(f, sq, z, w, x, c0, Bq, iters, prox, dc_c, pp)
-                                                              : run_chunk(f, sq, z, w, x, c0, Bq, iters, cnc, dc_c, pp);
+            if (e == hipSuccess) e = (sch.mixed && Bq >= 64) ? run_mixed(f, sq, z, w, x, c0, Bq, iters, prox, dc_c, pp)
+                                                              : run_chunk(f, sq, z, w, x, c0, Bq, iters, prox, dc_c, pp);
             if (q > 0 && e == hipSuccess) e = hipEventRecord(f->ev_join[q - 1], sq);
             if (q > 0 && e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join[q - 1], 0);
             c0 += Bq;
         }
         return e;
     }
-    const int chunk = fused_chunk(B);
+    int chunk = sch.chunk > 0 ? (sch.chunk & ~1) : B;
+    if (chunk < 2) chunk = 2;
     hipError_t e = hipSuccess;
     for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
-        e = run_chunk(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, cnc, dc_c, pp);
+        e = run_chunk(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
     return e;
 }
 

@@ -436,13 +436,10 @@ static hipError_t run5_chunk(Fused512* f, hipStream_t s, float* z, float* w, flo
 }
 
 hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
-                        float dc_c, ProxParams pp) {
+                        float dc_c, ProxParams pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
-    static int streams = -1, two_state = -1;
-    if (streams < 0) { const char* e = getenv("PNP_FUSED_STREAMS"); streams = e ? atoi(e) : 2; }
-    if (two_state < 0) { const char* e = getenv("PNP_FUSED_L1_TWO_STATE"); two_state = e ? atoi(e) : 0; }
-    const int prox = cnc ? 2 : (two_state ? 1 : 3);
-    if (streams >= 2 && B >= 32) {
+    const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
+    if (sch.queues >= 2 && sch.chunk <= 0 && B >= 32) {
         // two halves of the batch on two queues (see kernels_fused256.hip): kernel heads and tails overlap
         hipError_t e = hipSuccess;
         if (!f->side) {

@@ -73,6 +73,10 @@ class Engine:
     def set_fast_path(self, enable):
         _lib.check(self._L.pnp_set_fast_path(self._ctx, 1 if enable else 0))
 
+    def set_schedule(self, queues=2, mixed_launches=True, chunk=0):
+        """Scheduling of the fused loops (bit-identical results for every setting); see pnp_set_schedule."""
+        _lib.check(self._L.pnp_set_schedule(self._ctx, int(queues), 1 if mixed_launches else 0, int(chunk)))
+
     @property
     def path_name(self):
         return self._L.pnp_path_name(self._ctx).decode()
