@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   4
+#define PNP_ABI_VERSION   5
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -131,6 +131,10 @@ int pnp_Df(pnp_ctx* ctx, const float* x_dev, float* out_dev);
  * x_dev = NULL means the ctx-owned x of the last pnp_admm_*_run. */
 int pnp_metrics(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_device,
                 double* psnr_host, double* re_host);
+
+/* SSIM of img_E = x*255 vs gt per slice (utils/utils_image.py:570-615: Gaussian 11/1.5 window,
+ * valid region, gray images), computed in double on the device.  x_dev = NULL: the ctx-owned x. */
+int pnp_ssim(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_device, double* ssim_host);
 
 /* ---- fp64 validation context ---------------------------------------------------------------
  * The same loops (pnp_init_state, pnp_admm_l1_run, pnp_admm_cnc_run) with every buffer and every

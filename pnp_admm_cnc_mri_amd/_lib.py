@@ -55,13 +55,14 @@ SIGNATURES = {
     'pnp_get_state_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
     'pnp_download_x_f64': (C.c_int, [ctx_p, _vp, C.c_int]),
     'pnp_is_f64': (C.c_int, [ctx_p]),
+    'pnp_ssim': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p]),
     'pnp_timer_start': (C.c_int, [ctx_p]),
     'pnp_timer_stop': (C.c_int, [ctx_p, c_float_p]),
     'pnp_kernels_per_iteration': (C.c_int, [ctx_p]),
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -45,6 +45,7 @@ struct pnp_ctx {
     int32_t* mask_id = nullptr;       // [Bmax]
     uint8_t* gt = nullptr;            // [Bmax][H][W] (metrics, lazily)
     double* acc = nullptr;            // [Bmax][2]
+    double* ssim_part = nullptr;      // [Bmax][tiles] (lazily)
     void* stage = nullptr;            // staging for host inputs of synthesize
     size_t stage_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -128,6 +129,7 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = upload_twiddles();
+    if (e == hipSuccess) e = upload_gauss();
     if (e != hipSuccess) {
         pnp_ctx_destroy(c);
         return fail(e == hipErrorOutOfMemory ? PNP_E_NOMEM : PNP_E_HIP, "pnp_ctx_create: %s", hipGetErrorString(e));
@@ -153,7 +155,7 @@ int pnp_ctx_destroy(pnp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->fused) fused256_destroy(c->fused);
     if (c->fused5) fused512_destroy(c->fused5);
-    void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage,
+    void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage, c->ssim_part,
                     c->yd, c->workd, c->zd, c->wd, c->xd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -523,6 +525,35 @@ int pnp_metrics(pnp_ctx* c, const float* x, const uint8_t* gt, int gt_on_device,
         const double mse = h[2 * b] / (double)c->N;
         psnr[b] = (mse == 0.0) ? INFINITY : 20.0 * log10(255.0 / sqrt(mse));
         re[b] = sqrt(h[2 * b]) / sqrt(h[2 * b + 1]);
+    }
+    return PNP_OK;
+}
+
+int pnp_ssim(pnp_ctx* c, const float* x, const uint8_t* gt, int gt_on_device, double* ssim) {
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
+    if (!gt || !ssim) return fail(PNP_E_ARG, "pnp_ssim: null pointer");
+    if (!x) {
+        if (!c->have_x) return fail(PNP_E_STATE, "pnp_ssim: x_dev is null and the ctx holds no x yet");
+        x = c->x;
+    }
+    const uint8_t* d_gt = gt;
+    if (!gt_on_device) {
+        if (!c->gt) HIPCHK(hipMalloc((void**)&c->gt, (size_t)c->Bmax * c->N));
+        int rc = copy_in(c, c->gt, gt, (size_t)c->B * c->N, 0);
+        if (rc) return rc;
+        d_gt = c->gt;
+    }
+    const int tiles = ((c->W - 10 + 15) / 16) * ((c->H - 10 + 15) / 16);
+    if (!c->ssim_part) HIPCHK(hipMalloc((void**)&c->ssim_part, (size_t)c->Bmax * tiles * sizeof(double)));
+    HIPCHK(launch_ssim(c->stream, x, d_gt, c->ssim_part, c->B, c->H, c->W));
+    std::vector<double> h((size_t)c->B * tiles);
+    int rc = copy_out(c, h.data(), c->ssim_part, h.size() * sizeof(double), 0);
+    if (rc) return rc;
+    const double npix = (double)(c->H - 10) * (double)(c->W - 10);
+    for (int b = 0; b < c->B; ++b) {
+        double s = 0.0;
+        for (int t = 0; t < tiles; ++t) s += h[(size_t)b * tiles + t];
+        ssim[b] = s / npix;
     }
     return PNP_OK;
 }

@@ -68,6 +68,8 @@ hipError_t launch_combine(hipStream_t s, const float* z, const float* x, const f
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* o, size_t n);
 hipError_t launch_dual_clamp(hipStream_t s, float* x, float* z, float* w, size_t n);
 hipError_t launch_metrics(hipStream_t s, const float* x, const uint8_t* gt, double* acc /*[B][2]*/, int B, int N);
+hipError_t upload_gauss();
+hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double* partial /*[B][tiles]*/, int B, int H, int W);
 
 // How the fused loops are scheduled (scheduling only: results are bit-identical for every setting).
 struct FusedSchedule {

@@ -418,4 +418,72 @@ hipError_t launch_metrics(hipStream_t s, const float* x, const uint8_t* gt, doub
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// SSIM (utils/utils_image.py:593-615): 11-tap Gaussian (sigma 1.5) on the valid region, in double.
+// One workgroup per 16x16 tile of the (H-10)x(W-10) SSIM map: 26x26 patches of img_E = 255 x and
+// of the ground truth in LDS, separable filter of the five moment planes, per-tile partial sum
+// (host adds the tiles: deterministic, no float atomics).
+// ------------------------------------------------------------------------------------------
+__constant__ double c_gauss[11];
+
+hipError_t upload_gauss() {
+    double g[11], s = 0.0;
+    for (int i = 0; i < 11; ++i) { g[i] = exp(-((i - 5.0) * (i - 5.0)) / (2.0 * 1.5 * 1.5)); s += g[i]; }
+    for (int i = 0; i < 11; ++i) g[i] /= s;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g));
+}
+
+__global__ __launch_bounds__(256) void k_ssim(const float* x, const uint8_t* gt, double* partial, int H, int W, int tiles_x, int tiles_y) {
+    __shared__ double sx[26][26], sg[26][26];
+    __shared__ double hp[5][26][16];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int VH = H - 10, VW = W - 10;
+    const float* xb = x + (size_t)b * H * W;
+    const uint8_t* gb = gt + (size_t)b * H * W;
+    for (int i = tid; i < 26 * 26; i += 256) {
+        const int r = i / 26, c = i % 26;
+        const int yy = min(ty0 + r, H - 1), xx = min(tx0 + c, W - 1);
+        sx[r][c] = (double)xb[yy * W + xx] * 255.0;
+        sg[r][c] = (double)gb[yy * W + xx];
+    }
+    __syncthreads();
+    for (int i = tid; i < 26 * 16; i += 256) {                  // horizontal pass
+        const int r = i / 16, c = i % 16;
+        double m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const double a = sx[r][c + k], g = sg[r][c + k], wgt = c_gauss[k];
+            m1 += wgt * a; m2 += wgt * g; s11 += wgt * a * a; s22 += wgt * g * g; s12 += wgt * a * g;
+        }
+        hp[0][r][c] = m1; hp[1][r][c] = m2; hp[2][r][c] = s11; hp[3][r][c] = s22; hp[4][r][c] = s12;
+    }
+    __syncthreads();
+    const int r = tid >> 4, c = tid & 15;
+    double v = 0.0;
+    if (ty0 + r < VH && tx0 + c < VW) {
+        double m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const double wgt = c_gauss[k];
+            m1 += wgt * hp[0][r + k][c]; m2 += wgt * hp[1][r + k][c];
+            s11 += wgt * hp[2][r + k][c]; s22 += wgt * hp[3][r + k][c]; s12 += wgt * hp[4][r + k][c];
+        }
+        const double C1 = (0.01 * 255) * (0.01 * 255), C2 = (0.03 * 255) * (0.03 * 255);
+        const double m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+        v = ((2 * m12 + C1) * (2 * (s12 - m12) + C2)) / ((m11 + m22 + C1) * ((s11 - m11) + (s22 - m22) + C2));
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)b * tiles_x * tiles_y + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double* partial, int B, int H, int W) {
+    const int tx = (W - 10 + 15) / 16, ty = (H - 10 + 15) / 16;
+    hipLaunchKernelGGL(k_ssim, dim3(tx * ty, B), dim3(256), 0, s, x, gt, partial, H, W, tx, ty);
+    return hipGetLastError();
+}
+
 }  // namespace pnp

@@ -221,3 +221,10 @@ class Engine:
         _lib.check(self._L.pnp_metrics(self._ctx, _ptr(x_dev), _ptr(gt), 0,
                                        psnr.ctypes.data_as(_lib.c_double_p), re.ctypes.data_as(_lib.c_double_p)))
         return psnr, re
+
+    def ssim(self, x_dev, gt_u8):
+        """-> ssim[B] of img_E = x*255 against uint8 ground truth (utils/utils_image.py:570-615), on device."""
+        gt = _host(gt_u8, np.uint8)
+        out = np.empty(self.B, np.float64)
+        _lib.check(self._L.pnp_ssim(self._ctx, _ptr(x_dev), _ptr(gt), 0, out.ctypes.data_as(_lib.c_double_p)))
+        return out

@@ -92,7 +92,7 @@ class _Job:
         self.B = len(self.gt_u8) if self.gt_u8 is not None else len(self.y)
         self.noises = None if noises is None else np.asarray(noises)
         self.device = device
-        self.ssim = self.from_files if ssim is None else ssim
+        self.ssim = True if ssim is None else ssim
         self.log = log
         if self.log is None and (self.from_files or self.save_E):
             os.makedirs(self.E_path, exist_ok=True)
@@ -110,9 +110,9 @@ class _Job:
         eng.init_state()                                                                  # S4:103-109
         return eng
 
-    def finish(self, eng, x, x_dev=None, extra='', x_metric=None):
-        """S4:138-172: out list, optional PNGs, PSNR/SSIM/RE log lines, averages.
-        x_metric: the image the host-side SSIM is taken on (PnP: the uint8-quantised x, S6:314)."""
+    def finish(self, eng, x, x_dev=None, extra=''):
+        """S4:138-172: out list, optional PNGs, PSNR/SSIM/RE log lines, averages.  Metrics are
+        device reductions on x_dev (None = the ctx's x; PnP passes the uint8-quantised x, S6:314)."""
         A = np.zeros((self.H, self.W), dtype='uint8')
         out = [A] * max(22, self.B)
         psnr1 = [0] * max(22, self.B)
@@ -123,9 +123,7 @@ class _Job:
             psnr, re = eng.metrics(x_dev, self.gt_u8)                                     # device reductions
             info['psnr'], info['re'] = list(map(float, psnr)), list(map(float, re))
             if self.ssim:
-                xm = x if x_metric is None else x_metric
-                info['ssim'] = [float(_metrics.calculate_ssim(xm[n].astype(np.float64) * 255, self.gt_u8[n]))
-                                for n in range(self.B)]
+                info['ssim'] = list(map(float, eng.ssim(x_dev, self.gt_u8)))                  # device, double
             for n in range(self.B):
                 psnr1[n] = info['psnr'][n]
                 if self.log is not None and self.names is not None:

@@ -82,8 +82,7 @@ def _device_state(torch, eng, B, H, W, dev):
 def _finish_pnp(torch, job, eng, x, extra):
     """S6:314-351: img_E = uint8(round(x*255)); metrics on the quantised image."""
     xq = torch.round(x * 255.0) / 255.0
-    out, psnr1, info = job.finish(eng, x.reshape(job.B, job.H, job.W).cpu().numpy(), x_dev=xq.contiguous(),
-                                  extra=extra, x_metric=xq.reshape(job.B, job.H, job.W).cpu().numpy())
+    out, psnr1, info = job.finish(eng, x.reshape(job.B, job.H, job.W).cpu().numpy(), x_dev=xq.contiguous(), extra=extra)
     return out, psnr1, info
 
 

@@ -539,3 +539,27 @@ def test_schedules_are_bit_identical(P):
     for o in outs[1:]:
         for k in ('x', 'z', 'w', 'xl'):
             assert np.array_equal(outs[0][k], o[k]), k
+
+
+def test_device_ssim_matches_reference_definition(P, golden_inputs, golden_admm):
+    """pnp_ssim against the oracle's SSIM (valid-region Gaussian 11/1.5, utils_image.py:593-615) and
+    the authors' logged values for the committed presets (0.5877 / 0.5600)."""
+    gray = golden_inputs['gray']
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    out, info = P.ADMM_L1(mask, golden_inputs['noises'], images=gray[None], return_info=True, **P.PRESETS['ADMM_L1'])
+    assert abs(info['ssim'][0] - O.calculate_ssim(out[0] * 255, gray)) <= 1e-6
+    assert abs(info['ssim'][0] - 0.5877) <= 6e-5
+    out, info = P.ADMM_CNC(mask, golden_inputs['noises'], images=gray[None], return_info=True, **P.PRESETS['ADMM_CNC'])
+    assert abs(info['ssim'][0] - 0.5600) <= 6e-5
+    # batched, ragged tile edges (246 = 15*16 + 6) and a 512x512 case
+    rng = np.random.default_rng(1)
+    for H in (256, 512):
+        B = 3
+        x = rng.uniform(0, 1, (B, H, H)).astype(np.float32)
+        gt = rng.integers(0, 256, (B, H, H), dtype=np.uint8)
+        with P.Engine(H, H, Bmax=B) as eng:
+            eng.upload(np.zeros((B, H, H), np.complex64), np.ones((H, H), np.uint8))
+            import torch
+            s = eng.ssim(torch.from_numpy(x).cuda(), gt)
+        for b in range(B):
+            assert abs(s[b] - O.calculate_ssim(x[b].astype(np.float64) * 255, gt[b])) <= 1e-9
