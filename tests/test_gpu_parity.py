@@ -563,3 +563,30 @@ def test_device_ssim_matches_reference_definition(P, golden_inputs, golden_admm)
             s = eng.ssim(torch.from_numpy(x).cuda(), gt)
         for b in range(B):
             assert abs(s[b] - O.calculate_ssim(x[b].astype(np.float64) * 255, gt[b])) <= 1e-9
+
+
+def test_entry_point_reads_testset_and_writes_results_like_the_reference(P, golden_inputs, golden_admm, tmp_path):
+    """No `images=`: the solver lists testsets/<Set>, decodes the PNGs to gray, reconstructs all of
+    them in one batch, writes results/<Set>_dn_ADMM_CNC/*.png and appends the reference's log lines
+    (S4:62-94, 138-172)."""
+    import re
+    from PIL import Image
+    ts = tmp_path / 'testsets' / 'Set1'
+    ts.mkdir(parents=True)
+    gray = golden_inputs['gray']
+    Image.fromarray(gray).save(ts / '05.png')
+    Image.fromarray(gray[::-1].copy()).save(ts / '06.png')
+    res = tmp_path / 'results'
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    out = P.ADMM_CNC(mask, golden_inputs['noises'], testsets=str(tmp_path / 'testsets'), results=str(res),
+                     **P.PRESETS['ADMM_CNC'])
+    assert len(out) == 22 and rel_l2(out[0], golden_admm['cnc_random30_it50']) <= 1e-4
+    assert out[1].shape == (256, 256) and out[2].dtype == np.uint8
+    d = res / 'Set1_dn_ADMM_CNC'
+    assert sorted(p.name for p in d.glob('*.png')) == ['05_ADMM CNC.png', '06_ADMM CNC.png']
+    log = (d / 'Set1_dn_ADMM_CNC.log').read_text()
+    m = re.search(r'05\.png - PSNR: (\d+\.\d{4}) dB; SSIM: (\d\.\d{4}) ; RE: (\d\.\d{4})\.', log)
+    assert m and abs(float(m.group(1)) - 24.5765) <= 0.01 and abs(float(m.group(2)) - 0.5600) <= 1e-4 and abs(float(m.group(3)) - 0.1870) <= 1e-4
+    assert re.search(r'------> testset_name: \(Set1\), Average PSNR:\(\d+\.\d{3}\)dB, Average ssim : \(\d\.\d{3}\), Average re : \(\d\.\d{3}\) \)', log)
+    saved = np.asarray(Image.open(d / '05_ADMM CNC.png')).astype(np.float64)
+    assert np.abs(saved - np.clip(np.rint(out[0] * 255), 0, 255)).max() <= 1
