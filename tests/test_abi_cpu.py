@@ -60,3 +60,21 @@ def test_engine_without_gpu_fails_loudly():
     import pnp_admm_cnc_mri_amd as P
     with pytest.raises(_lib.PnpError):
         P.Engine(256, 256, 1)
+
+
+def _build_consumer(tmp_path):
+    import subprocess
+    exe = str(tmp_path / 'abi_consumer')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'tests', 'host', 'abi_consumer.c'), '-o', exe,
+                           '-L', os.path.dirname(_lib.LIB_PATH), '-lpnpmri', '-lm',
+                           '-Wl,-rpath,' + os.path.dirname(_lib.LIB_PATH)])
+    return exe
+
+
+def test_plain_c_consumer_links_and_gets_error_codes(tmp_path):
+    """include/pnp_mri.h compiles as C99 and a gcc-built program drives the library."""
+    import subprocess
+    exe = _build_consumer(tmp_path)
+    out = subprocess.check_output([exe]).decode()
+    assert out.startswith('devices ')

@@ -590,3 +590,27 @@ def test_entry_point_reads_testset_and_writes_results_like_the_reference(P, gold
     assert re.search(r'------> testset_name: \(Set1\), Average PSNR:\(\d+\.\d{3}\)dB, Average ssim : \(\d\.\d{3}\), Average re : \(\d\.\d{3}\) \)', log)
     saved = np.asarray(Image.open(d / '05_ADMM CNC.png')).astype(np.float64)
     assert np.abs(saved - np.clip(np.rint(out[0] * 255), 0, 255)).max() <= 1
+
+
+def test_plain_c_consumer_runs_the_loop(P, tmp_path):
+    """The gcc-built C program (tests/host/abi_consumer.c) runs synthesis + 5 L1 iterations through
+    the C ABI; the Python binding must give the same checksum on the same inputs."""
+    import subprocess
+    from test_abi_cpu import _build_consumer
+    exe = _build_consumer(tmp_path)
+    out = subprocess.check_output([exe, 'run']).decode()
+    chk = float(out.strip().split()[-1])
+    B, H, W = 2, 256, 256
+    img = np.zeros((B, H, W), np.float32)
+    for b in range(B):
+        img[b, 96:160, 64 + 16 * b:192] = 0.5 + 0.25 * b
+    mask = np.zeros((H, W), np.uint8)
+    rows = [r for r in range(H) if r % 2 == 0 or r < 8 or r > H - 8]
+    mask[rows, :] = 1
+    with P.Engine(H, W, Bmax=B) as eng:
+        eng.synthesize(img, np.zeros((H, W), np.complex64), mask)
+        eng.init_state()
+        eng.admm_l1(5, 0.1, 0.015)
+        x = eng.x()
+    assert abs(float(x.astype(np.float64).sum()) - chk) <= 1e-6 * abs(chk)
+    assert 'path fused' in out
