@@ -183,6 +183,7 @@ def main():
             'config': {'workload': 'ADMM_%s, %d synthetic %dx%d complex64 slices per GPU, %s, S4:176 presets'
                                    % (args.solver.upper(), B, H, W, 'Q_Random30' if H == 256 else 'seeded mask bank of 3'),
                        'slices_per_gpu': B, 'path': eng.path_name,
+                       'launches_per_iteration': eng.kernels_per_iteration,
                        'queues': int(os.environ.get('PNP_FUSED_STREAMS', '2')) if eng.path_name == 'fused' else 1,
                        'mixed_row_col_launches': (os.environ.get('PNP_FUSED_SCHED', '1') == '1') if eng.path_name == 'fused' else False},
             'slice_iterations_per_s': value * B_PER_GPU,

@@ -157,7 +157,8 @@ int pnp_timer_start(pnp_ctx* ctx);
 int pnp_timer_stop(pnp_ctx* ctx, float* elapsed_ms);    /* records, synchronises, returns ms */
 
 /* ---- introspection ------------------------------------------------------------------------ */
-/* kernels launched per ADMM iteration on the current path, and which path ("generic"|"fused") */
+/* launches per batched ADMM iteration on the current path and schedule, and which path
+ * ("generic" | "fused") the loops take for the uploaded problem */
 int         pnp_kernels_per_iteration(pnp_ctx* ctx);
 const char* pnp_path_name(pnp_ctx* ctx);
 

@@ -92,7 +92,6 @@ hipError_t fused256_run(Fused256*, hipStream_t s, float* z, float* w, float* x, 
                         bool cnc, float dc_c, ProxParams p, const FusedSchedule& sch);
 // one data-consistency step on caller pointers
 hipError_t fused256_dc(Fused256*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
-int        fused256_kernels_per_iteration();
 
 // fused 512x512 path (kernels_fused512.hip): same scheme with 32-lane transforms
 struct Fused512;

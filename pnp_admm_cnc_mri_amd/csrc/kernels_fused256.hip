@@ -1,4 +1,6 @@
-// Fused gfx950 kernels for 256x256 slices: one ADMM iteration = 2 launches.
+// Fused gfx950 kernels for 256x256 slices: one ADMM iteration = 2 launches per part of the batch
+// (sequential schedule: k_frows + k_fcols; default schedule: two k_fmixed launches per queue, each
+// holding the row workgroups of one half of the part and the column workgroups of the other).
 //
 //   k_frows : per 16 rows of a slice PAIR (a = 2p, b = 2p+1, carried as c = v_a + i v_b):
 //             [inverse row FFT of T -> x = |Re|,|Im| / 65536 -> L1/CNC z-update -> dual update]
@@ -16,8 +18,12 @@
 // FFT-256 = 16 lanes x 16 points (radix-16 in registers, one 16x16 transpose through LDS).
 //   rows   : lanes of a 16-group are consecutive (one row each), global access is 16 B/lane
 //            through an LDS staging tile;
-//   columns: a group's lanes sit 16 apart (lane = k2_local + 16*t_quad, 4 waves) so every
-//            global access instruction covers 128-B row segments of 16 neighbouring columns.
+//   columns: a group's lanes sit 16 apart (lane = pair_local + 16*t_quad, 4 waves) so every global
+//            access instruction covers 256-B row segments: 16 neighbouring {C[r][q], C[r][256-q]}
+//            elements of 16 bytes (mirrored columns are stored side by side, see phi()).
+// The W256 twiddle table is staged in LDS and read where used; keeping it in 32 VGPRs cost a wave
+// per SIMD.  Everything is compiled with -ffp-contract=off and explicit fmaf (fft16.h), so all
+// kernel variants and schedules round identically.
 #include "internal.h"
 #include "fused_layout.h"
 #include <math.h>
@@ -586,6 +592,5 @@ hipError_t fused256_dc(Fused256* f, hipStream_t s, const float* z, const float* 
     return e;
 }
 
-int fused256_kernels_per_iteration() { return 2; }
 
 }  // namespace pnp
