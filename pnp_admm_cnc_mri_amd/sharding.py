@@ -58,3 +58,47 @@ def run_sharded(solve_shard, B_total, group=None, dst=0):
         return solve_shard(0, B_total)
     lo, hi = shard_range(B_total, dist.get_world_size(group), dist.get_rank(group))
     return gather_slices(solve_shard(lo, hi), B_total, dst=dst, group=group)
+
+
+def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0, group=None, gather_device=None,
+                  **solver_kwargs):
+    """Run one of the entry points (ADMM_L1, ADMM_CNC, PNP_ADMM_*_D: anything with the
+    `(…, mask, noises, images=, y=, mask_id=, **opts) -> out | (out, …)` shape, pre-bound with
+    `functools.partial` when it takes leading model names) on this rank's contiguous block of slices
+    and gather the reconstructions on `dst`.
+
+    Every rank passes the SAME full `images` / `y` / `mask_id`; returns a float32 array
+    [B_total, H, W] on `dst`, None elsewhere.  With no process group it is a plain call.
+    gather_device: torch device for the collective (default: cuda:<local device> under nccl, cpu under gloo).
+    """
+    import torch
+    import torch.distributed as dist
+    src = images if images is not None else y
+    if src is None:
+        raise ValueError('solve_sharded needs images= or y= (file-based inputs cannot be sharded by index)')
+    B_total = len(src)
+    if not (dist.is_available() and dist.is_initialized()):
+        lo, hi, world = 0, B_total, 1
+    else:
+        world = dist.get_world_size(group)
+        lo, hi = shard_range(B_total, world, dist.get_rank(group))
+    kw = dict(solver_kwargs)
+    if images is not None:
+        kw['images'] = np.asarray(images)[lo:hi]
+    if y is not None:
+        kw['y'] = np.asarray(y)[lo:hi]
+    if mask_id is not None:
+        kw['mask_id'] = np.asarray(mask_id)[lo:hi]
+    if hi > lo:
+        res = solver(mask, noises, **kw)
+        out = res[0] if isinstance(res, tuple) else res
+        x_local = np.stack([np.asarray(out[n], dtype=np.float32) for n in range(hi - lo)])
+    else:
+        m = np.asarray(mask)
+        x_local = np.zeros((0,) + m.shape[-2:], np.float32)
+    if world == 1:
+        return x_local
+    if gather_device is None:
+        gather_device = torch.device('cuda', kw.get('device', 0)) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    x_all = gather_slices(torch.from_numpy(x_local).to(gather_device), B_total, dst=dst, group=group)
+    return None if x_all is None else x_all.cpu().numpy()

@@ -77,6 +77,58 @@ def test_sharded_equals_single_process(world, B):
     assert got.shape == ref.shape and np.array_equal(got, ref)
 
 
+def _fake_solver(mask, noises, images=None, y=None, mask_id=None, **opts):
+    """same call shape as ADMM_L1: returns the reference-style list (22 slots) of float64 arrays."""
+    out = [np.zeros(mask.shape[-2:], np.uint8)] * max(22, len(y))
+    for n in range(len(y)):
+        k = 0 if mask_id is None else int(mask_id[n])
+        out[n] = O.admm_l1(y[n], mask[k], opts.get('iter_num', 2))
+    return out
+
+
+def _worker_solver(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        x = sharding.solve_sharded(_fake_solver, *_solver_problem()[:2], y=_solver_problem()[2], mask_id=_solver_problem()[3], iter_num=2)
+        if rank == 0:
+            q.put(x)
+        else:
+            assert x is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _solver_problem():
+    rng = np.random.default_rng(0)
+    masks = (rng.uniform(size=(2, 64, 64)) < 0.4).astype(np.float64)
+    masks[:, 0, 0] = 1
+    B = 5
+    mid = np.arange(B) % 2
+    y = np.stack([np.fft.fft2(np.random.default_rng(b).uniform(0, 1, (64, 64))) * masks[mid[b]] for b in range(B)])
+    return masks, None, y, mid
+
+
+def test_solve_sharded_entry_point_shape():
+    """An entry-point-shaped solver sharded over 2 ranks (uneven: 3 + 2 slices, per-slice masks)
+    equals the single-process call."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_solver, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    masks, _, y, mid = _solver_problem()
+    ref = sharding.solve_sharded(_fake_solver, masks, None, y=y, mask_id=mid, iter_num=2)
+    assert got.shape == (5, 64, 64) and np.array_equal(got, ref)
+
+
 def test_run_sharded_without_process_group():
     x = sharding.run_sharded(_solve, 3)
     assert x.shape == (3, 64, 64)
