@@ -124,7 +124,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('PNP_BENCH_FORCE_DIST') == '1':     # the env hook exercises RCCL with one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.rehearse_gloo:
