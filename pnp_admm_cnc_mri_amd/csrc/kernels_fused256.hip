@@ -26,6 +26,7 @@
 // kernel variants and schedules round identically.
 #include "internal.h"
 #include "fused_layout.h"
+#include "fused_pointwise.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -85,18 +86,6 @@ __global__ __launch_bounds__(256) void k_fprepare(const c32* y, const uint8_t* m
 // ------------------------------------------------------------------------------------------
 // rows
 // ------------------------------------------------------------------------------------------
-struct FRowArgs {
-    c32* T;
-    const float* z_in;
-    const float* w_in;
-    float* z_out;
-    float* w_out;
-    float* x_out;
-    int B;
-    float scale;
-    ProxCoef prox;
-    int u_first;
-};
 
 // physical column of k-space column k inside a row of T: mirrored columns sit side by side so the
 // column kernel moves {C[r][q], C[r][256-q]} as ONE aligned 16-byte access:
@@ -127,11 +116,7 @@ __device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32* twl, c32* re
     fft256_tail<INV>(a);
 }
 
-// PROX: 0 none, 1 L1, 2 CNC, 3 L1 in single-state form: for L1, z = soft(u) and w = u - z are both
-// functions of u = x + w_old, so between the first and the last iteration of a run only u is kept
-// (in the w buffer): 8 N instead of 16 N state bytes per slice-iteration.  w_old is recomputed as
-// u - soft(u) -- the very expression that produces the stored w -- so results are bit-identical
-// to the two-state form.  p.u_first = 1 while the w buffer still holds a genuine w.
+// PROX: see fused_pointwise.h
 constexpr int ROWS_LDS = 16 * XP + 256;      // c32 elements of LDS the row body needs
 
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
@@ -167,80 +152,7 @@ __device__ __forceinline__ void frows_body(const FRowArgs& p, const int bid, c32
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + 256 * i, row = idx >> 6, n4 = (idx & 63) * 4;
         const size_t off = (size_t)(r0 + row) * 256 + n4;
-        float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
-        if (HAS_INV) {
-            const float4 c01 = *reinterpret_cast<const float4*>(&lds[row * RP + n4]);
-            const float4 c23 = *reinterpret_cast<const float4*>(&lds[row * RP + n4 + 2]);
-            xa[0] = fabsf(c01.x) * p.scale; xb[0] = fabsf(c01.y) * p.scale;
-            xa[1] = fabsf(c01.z) * p.scale; xb[1] = fabsf(c01.w) * p.scale;
-            xa[2] = fabsf(c23.x) * p.scale; xb[2] = fabsf(c23.y) * p.scale;
-            xa[3] = fabsf(c23.z) * p.scale; xb[3] = fabsf(c23.w) * p.scale;
-        }
-        float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
-        if (PROX == 3) {
-            const float4 q1 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * 65536 + off);
-            wa[0] = q1.x; wa[1] = q1.y; wa[2] = q1.z; wa[3] = q1.w;
-            if (has_b) {
-                const float4 q2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * 65536 + off);
-                wb[0] = q2.x; wb[1] = q2.y; wb[2] = q2.z; wb[3] = q2.w;
-            }
-            float ua[4], ub[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!p.u_first) {                        // buffer holds u_old: w_old = u_old - soft(u_old)
-                    wa[q] = wa[q] - soft_thr(wa[q], p.prox.thr);
-                    wb[q] = wb[q] - soft_thr(wb[q], p.prox.thr);
-                }
-                ua[q] = xa[q] + wa[q];
-                ub[q] = xb[q] + wb[q];
-                za[q] = soft_thr(ua[q], p.prox.thr); wa[q] = ua[q] - za[q];
-                zb[q] = soft_thr(ub[q], p.prox.thr); wb[q] = ub[q] - zb[q];
-            }
-            if (HAS_FWD) {                               // mid-run: keep only u
-                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * 65536 + off) = make_float4(ua[0], ua[1], ua[2], ua[3]);
-                if (has_b) *reinterpret_cast<float4*>(p.w_out + (size_t)sb * 65536 + off) = make_float4(ub[0], ub[1], ub[2], ub[3]);
-            } else {                                     // end of run: materialise z and w
-                *reinterpret_cast<float4*>(p.z_out + (size_t)sa * 65536 + off) = make_float4(za[0], za[1], za[2], za[3]);
-                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * 65536 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
-                if (has_b) {
-                    *reinterpret_cast<float4*>(p.z_out + (size_t)sb * 65536 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
-                    *reinterpret_cast<float4*>(p.w_out + (size_t)sb * 65536 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
-                }
-            }
-        }
-        if ((PROX != 0 && PROX != 3) || !HAS_INV) {
-            const float4 v1 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sa * 65536 + off);
-            const float4 v2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * 65536 + off);
-            za[0] = v1.x; za[1] = v1.y; za[2] = v1.z; za[3] = v1.w;
-            wa[0] = v2.x; wa[1] = v2.y; wa[2] = v2.z; wa[3] = v2.w;
-            if (has_b) {
-                const float4 v3 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sb * 65536 + off);
-                const float4 v4 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * 65536 + off);
-                zb[0] = v3.x; zb[1] = v3.y; zb[2] = v3.z; zb[3] = v3.w;
-                wb[0] = v4.x; wb[1] = v4.y; wb[2] = v4.z; wb[3] = v4.w;
-            }
-        }
-        if (PROX == 1 || PROX == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], p.prox); prox_l1_pt(xb[q], zb[q], wb[q], p.prox); }
-                else           { prox_cnc_pt(xa[q], za[q], wa[q], p.prox); prox_cnc_pt(xb[q], zb[q], wb[q], p.prox); }
-            }
-            *reinterpret_cast<float4*>(p.z_out + (size_t)sa * 65536 + off) = make_float4(za[0], za[1], za[2], za[3]);
-            *reinterpret_cast<float4*>(p.w_out + (size_t)sa * 65536 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
-            if (has_b) {
-                *reinterpret_cast<float4*>(p.z_out + (size_t)sb * 65536 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
-                *reinterpret_cast<float4*>(p.w_out + (size_t)sb * 65536 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
-            }
-        }
-        if (WRITE_X) {
-            *reinterpret_cast<float4*>(p.x_out + (size_t)sa * 65536 + off) = make_float4(xa[0], xa[1], xa[2], xa[3]);
-            if (has_b) *reinterpret_cast<float4*>(p.x_out + (size_t)sb * 65536 + off) = make_float4(xb[0], xb[1], xb[2], xb[3]);
-        }
-        if (HAS_FWD) {
-            *reinterpret_cast<float4*>(&lds[row * RP + n4]) = make_float4(za[0] - wa[0], zb[0] - wb[0], za[1] - wa[1], zb[1] - wb[1]);
-            *reinterpret_cast<float4*>(&lds[row * RP + n4 + 2]) = make_float4(za[2] - wa[2], zb[2] - wb[2], za[3] - wa[3], zb[3] - wb[3]);
-        }
+        pointwise4<HAS_INV, PROX, HAS_FWD, WRITE_X>(p, &lds[row * RP + n4], (size_t)sa * 65536 + off, (size_t)sb * 65536 + off, has_b);
     }
 
     if (HAS_FWD) {

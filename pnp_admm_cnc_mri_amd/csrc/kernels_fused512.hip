@@ -12,6 +12,7 @@
 // HBM bytes per slice-iteration: 36 N, as at 256x256.
 #include "internal.h"
 #include "fused_layout.h"
+#include "fused_pointwise.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -79,18 +80,6 @@ __global__ __launch_bounds__(256) void k5_prepare(const c32* y, const uint8_t* m
 // ------------------------------------------------------------------------------------------
 // rows
 // ------------------------------------------------------------------------------------------
-struct F5RowArgs {
-    c32* T;
-    const float* z_in;
-    const float* w_in;
-    float* z_out;
-    float* w_out;
-    float* x_out;
-    int B;
-    float scale;
-    ProxCoef prox;
-    int u_first;
-};
 
 constexpr int RP5 = 520;     // LDS pitch (c32) of a staged row
 constexpr int XP5 = 544;     // exchange region per 32-lane group: 16 runs of 34
@@ -119,7 +108,7 @@ __device__ __forceinline__ void xchg_k2t(c32 (&a)[16], c32* region, int t) {
 
 // PROX as in kernels_fused256.hip: 0 none, 1 L1 (z and w), 2 CNC, 3 L1 single-state
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__global__ __launch_bounds__(256) void k5_rows(F5RowArgs p) {
+__global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
     __shared__ __attribute__((aligned(16))) c32 lds[ROWS5_LDS];
     const int tid = threadIdx.x, g = tid >> 5, t = tid & 31;
     const int k2 = t >> 1, h = t & 1;
@@ -161,80 +150,7 @@ __global__ __launch_bounds__(256) void k5_rows(F5RowArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + 256 * i, row = idx >> 7, n4 = (idx & 127) * 4;
         const size_t off = (size_t)(r0 + row) * 512 + n4;
-        float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
-        if (HAS_INV) {
-            const float4 c01 = *reinterpret_cast<const float4*>(&lds[row * RP5 + n4]);
-            const float4 c23 = *reinterpret_cast<const float4*>(&lds[row * RP5 + n4 + 2]);
-            xa[0] = fabsf(c01.x) * p.scale; xb[0] = fabsf(c01.y) * p.scale;
-            xa[1] = fabsf(c01.z) * p.scale; xb[1] = fabsf(c01.w) * p.scale;
-            xa[2] = fabsf(c23.x) * p.scale; xb[2] = fabsf(c23.y) * p.scale;
-            xa[3] = fabsf(c23.z) * p.scale; xb[3] = fabsf(c23.w) * p.scale;
-        }
-        float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
-        if (PROX == 3) {
-            const float4 q1 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * NN5 + off);
-            wa[0] = q1.x; wa[1] = q1.y; wa[2] = q1.z; wa[3] = q1.w;
-            if (has_b) {
-                const float4 q2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * NN5 + off);
-                wb[0] = q2.x; wb[1] = q2.y; wb[2] = q2.z; wb[3] = q2.w;
-            }
-            float ua[4], ub[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!p.u_first) {
-                    wa[q] = wa[q] - soft_thr(wa[q], p.prox.thr);
-                    wb[q] = wb[q] - soft_thr(wb[q], p.prox.thr);
-                }
-                ua[q] = xa[q] + wa[q];
-                ub[q] = xb[q] + wb[q];
-                za[q] = soft_thr(ua[q], p.prox.thr); wa[q] = ua[q] - za[q];
-                zb[q] = soft_thr(ub[q], p.prox.thr); wb[q] = ub[q] - zb[q];
-            }
-            if (HAS_FWD) {
-                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * NN5 + off) = make_float4(ua[0], ua[1], ua[2], ua[3]);
-                if (has_b) *reinterpret_cast<float4*>(p.w_out + (size_t)sb * NN5 + off) = make_float4(ub[0], ub[1], ub[2], ub[3]);
-            } else {
-                *reinterpret_cast<float4*>(p.z_out + (size_t)sa * NN5 + off) = make_float4(za[0], za[1], za[2], za[3]);
-                *reinterpret_cast<float4*>(p.w_out + (size_t)sa * NN5 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
-                if (has_b) {
-                    *reinterpret_cast<float4*>(p.z_out + (size_t)sb * NN5 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
-                    *reinterpret_cast<float4*>(p.w_out + (size_t)sb * NN5 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
-                }
-            }
-        }
-        if ((PROX != 0 && PROX != 3) || !HAS_INV) {
-            const float4 v1 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sa * NN5 + off);
-            const float4 v2 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sa * NN5 + off);
-            za[0] = v1.x; za[1] = v1.y; za[2] = v1.z; za[3] = v1.w;
-            wa[0] = v2.x; wa[1] = v2.y; wa[2] = v2.z; wa[3] = v2.w;
-            if (has_b) {
-                const float4 v3 = *reinterpret_cast<const float4*>(p.z_in + (size_t)sb * NN5 + off);
-                const float4 v4 = *reinterpret_cast<const float4*>(p.w_in + (size_t)sb * NN5 + off);
-                zb[0] = v3.x; zb[1] = v3.y; zb[2] = v3.z; zb[3] = v3.w;
-                wb[0] = v4.x; wb[1] = v4.y; wb[2] = v4.z; wb[3] = v4.w;
-            }
-        }
-        if (PROX == 1 || PROX == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], p.prox); prox_l1_pt(xb[q], zb[q], wb[q], p.prox); }
-                else           { prox_cnc_pt(xa[q], za[q], wa[q], p.prox); prox_cnc_pt(xb[q], zb[q], wb[q], p.prox); }
-            }
-            *reinterpret_cast<float4*>(p.z_out + (size_t)sa * NN5 + off) = make_float4(za[0], za[1], za[2], za[3]);
-            *reinterpret_cast<float4*>(p.w_out + (size_t)sa * NN5 + off) = make_float4(wa[0], wa[1], wa[2], wa[3]);
-            if (has_b) {
-                *reinterpret_cast<float4*>(p.z_out + (size_t)sb * NN5 + off) = make_float4(zb[0], zb[1], zb[2], zb[3]);
-                *reinterpret_cast<float4*>(p.w_out + (size_t)sb * NN5 + off) = make_float4(wb[0], wb[1], wb[2], wb[3]);
-            }
-        }
-        if (WRITE_X) {
-            *reinterpret_cast<float4*>(p.x_out + (size_t)sa * NN5 + off) = make_float4(xa[0], xa[1], xa[2], xa[3]);
-            if (has_b) *reinterpret_cast<float4*>(p.x_out + (size_t)sb * NN5 + off) = make_float4(xb[0], xb[1], xb[2], xb[3]);
-        }
-        if (HAS_FWD) {
-            *reinterpret_cast<float4*>(&lds[row * RP5 + n4]) = make_float4(za[0] - wa[0], zb[0] - wb[0], za[1] - wa[1], zb[1] - wb[1]);
-            *reinterpret_cast<float4*>(&lds[row * RP5 + n4 + 2]) = make_float4(za[2] - wa[2], zb[2] - wb[2], za[3] - wa[3], zb[3] - wb[3]);
-        }
+        pointwise4<HAS_INV, PROX, HAS_FWD, WRITE_X>(p, &lds[row * RP5 + n4], (size_t)sa * NN5 + off, (size_t)sb * NN5 + off, has_b);
     }
 
     if (HAS_FWD) {
@@ -399,7 +315,7 @@ hipError_t fused512_prepare(Fused512* f, hipStream_t s, const float2* y, const u
 }
 
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-static hipError_t launch5_rows(hipStream_t s, int np, const F5RowArgs& a) {
+static hipError_t launch5_rows(hipStream_t s, int np, const FRowArgs& a) {
     hipLaunchKernelGGL((k5_rows<HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 64), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -418,7 +334,7 @@ static hipError_t run5_chunk(Fused512* f, hipStream_t s, float* z, float* w, flo
                              int prox, float dc_c, const ProxParams& pp) {
     const int np = (Bc + 1) / 2, pair0 = c0 / 2;
     const size_t so = (size_t)c0 * NN5;
-    F5RowArgs a;
+    FRowArgs a;
     a.T = f->T + (size_t)pair0 * NN5;
     a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
     a.scale = 1.0f / (float)NN5; a.prox = to_coef5(pp); a.u_first = 1;
@@ -462,7 +378,7 @@ hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x
 
 hipError_t fused512_dc(Fused512* f, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c) {
     const int np = (B + 1) / 2;
-    F5RowArgs a;
+    FRowArgs a;
     a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = nullptr; a.w_out = nullptr; a.x_out = x; a.B = B;
     a.scale = 1.0f / (float)NN5; a.prox = ProxCoef{}; a.u_first = 1;
     hipError_t e = launch5_rows<false, 0, true, false>(s, np, a);
