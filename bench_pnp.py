@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
     ap.add_argument('--channels-last', action='store_true')
+    ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'])
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
     args = ap.parse_args()
     fam = D.family(args.model)
@@ -44,7 +45,7 @@ def main():
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
-    den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch).to(dev)
+    den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype).to(dev)
     eng = P.Engine(256, 256, Bmax=B)
     eng.synthesize(img, noise, mask)
     eng.init_state()

@@ -15,6 +15,7 @@ save_E=, device=, return_info=  as in solvers.py, plus
     model_zoo='model_zoo'   directory of KAIR .pth files (S6:107-109)
     model= / model2=        an nn.Module (or state_dict) instead of a file
     cnn_batch=64            slices per CNN forward (activation memory)
+    cnn_dtype=None          None = float32 (parity); 'bf16'/'fp16' = autocast throughput mode, off parity
 """
 import os
 
@@ -42,7 +43,7 @@ PRESETS = {
 }
 
 
-def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, device):
+def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, device, cnn_dtype=None):
     """The model-zoo switch of S6:129-217: build by name, load weights, eval, no grad, to device."""
     import torch
     net, nlm, scheduled = D.build(model_name)
@@ -68,7 +69,8 @@ def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, d
         _, s = pnp.get_rho_sigma(sigma=max(0.255 / 255., nlm), iter_num=iter_num, modelSigma1=49,
                                  modelSigma2=nlm * 255., w=1.0)
         sigmas = torch.tensor(s)
-    return D.Denoiser(model_name, net, nlm, sigmas=sigmas, noises=noises, x8=x8, bank=bank, cnn_batch=cnn_batch).to(device)
+    return D.Denoiser(model_name, net, nlm, sigmas=sigmas, noises=noises, x8=x8, bank=bank, cnn_batch=cnn_batch,
+                      cnn_dtype=cnn_dtype).to(device)
 
 
 def _device_state(torch, eng, B, H, W, dev):
@@ -88,7 +90,7 @@ def _finish_pnp(torch, job, eng, x, extra):
 
 def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                    testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
-                   model_zoo='model_zoo', model=None, cnn_batch=64, **PNP_ADMM_CNC_D_opts):
+                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, **PNP_ADMM_CNC_D_opts):
     """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
     import torch
     alpha = PNP_ADMM_CNC_D_opts.get('alpha', 0.4)          # S6:85-89
@@ -99,7 +101,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
     dev = torch.device('cuda', device)
     job = _Job(mask, noises, model_name, 'PNP_ADMM_CNC_D', images, y, mask_id, testsets, testset_name, results,
                save_E, device)
-    den = _load_model(model_name, model, model_zoo, iter_num, noises, False, cnn_batch, dev)   # x8 = False, S6:93
+    den = _load_model(model_name, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)   # x8 = False, S6:93
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
         eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         B, H, W = job.B, job.H, job.W
@@ -123,7 +125,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
 def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
                        testsets='testsets', testset_name='Set1', results='results', save_E=None, device=0,
                        return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
-                       faithful_model2_path=True, **opts):
+                       cnn_dtype=None, faithful_model2_path=True, **opts):
     """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
     `faithful_model2_path`: the reference loads model_path1 into BOTH nets (S6:435) although it logs
     path 2; True reproduces that, False loads model_name2's own weights."""
@@ -136,11 +138,11 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
     dev = torch.device('cuda', device)
     job = _Job(mask, noises, model_name1 + '_' + model_name2, 'PNP_ADMM_CNC_DnCNN', images, y, mask_id, testsets,
                testset_name, results, save_E, device)
-    den1 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev)
+    den1 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)
     if faithful_model2_path and model2 is None:
-        den2 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev)
+        den2 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)
     else:
-        den2 = _load_model(model_name2, model2, model_zoo, iter_num, noises, False, cnn_batch, dev)
+        den2 = _load_model(model_name2, model2, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
         eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         B, H, W = job.B, job.H, job.W
@@ -160,7 +162,7 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
 
 def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                   testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
-                  model_zoo='model_zoo', model=None, cnn_batch=64, **PNP_ADMM_L1_D_opts):
+                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, **PNP_ADMM_L1_D_opts):
     """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
     import torch
     iter_num = PNP_ADMM_L1_D_opts.get('iter_num', 20)      # S3:83-84
@@ -170,7 +172,7 @@ def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, t
     x8 = fam in ('drunet', 'ffdnet')                       # x8 = True (S3:87) survives only there (S3:130,142,181)
     job = _Job(mask, noises, model_name, 'PNP_ADMM_L1_D', images, y, mask_id, testsets, testset_name, results,
                save_E, device)
-    den = _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, dev)
+    den = _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, dev, cnn_dtype)
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
         eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         B, H, W = job.B, job.H, job.W
