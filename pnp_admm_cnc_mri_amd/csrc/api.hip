@@ -610,7 +610,7 @@ int pnp_timer_stop(pnp_ctx* c, float* ms) {
 int pnp_kernels_per_iteration(pnp_ctx* c) {
     if (!c) return 0;
     if (!use_fused(c)) return 3;                      // generic: rows, columns, rows
-    const int q = (c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
+    const int q = (c->fused5 || c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
     return 2 * q;                                     // two launches per queue and batched iteration
 }
 const char* pnp_path_name(pnp_ctx* c) { return (c && use_fused(c)) ? "fused" : "generic"; }
