@@ -99,7 +99,7 @@ PNP_HD void fft256_tail(c32 (&a)[16]) { dft16<INV>(a); }
 // "B" structure (k-layout in, t-layout out) is its transposed flow graph (the DFT matrix is
 // symmetric):  butterfly -> W32^(q h) -> dft16 -> exchange -> W512^(t k2) -> dft16.
 // INV conjugates every twiddle, i.e. selects the direction of the transform; both structures
-// serve both directions.  tw = W512 table (forward values), tw[16 q h] = W32^(q h).
+// serve both directions.  tw = W512 table (forward values); W32^(q h) comes from literals.
 // ----------------------------------------------------------------------------------------------
 template <bool INV>
 PNP_HD void fft512_a1(c32 (&a)[16], const c32* tw, int t) {            // before the exchange
@@ -107,18 +107,25 @@ PNP_HD void fft512_a1(c32 (&a)[16], const c32* tw, int t) {            // before
 #pragma unroll
     for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[t * k]);
 }
+// W32^q = exp(-2 pi i q / 32) as compile-time constants (instruction literals: no table read, no
+// register held); the h = 0 lane multiplies by 1.
+PNP_HD c32 w32_or_one(int q, int h) {
+    constexpr float C[16] = {1.0f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f, 0.382683426f, 0.195090324f, 6.12323426e-17f, -0.195090324f, -0.382683426f, -0.555570245f, -0.707106769f, -0.831469595f, -0.923879504f, -0.980785251f};
+    constexpr float S[16] = {0.0f, 0.195090324f, 0.382683426f, 0.555570245f, 0.707106769f, 0.831469595f, 0.923879504f, 0.980785251f, 1.0f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f, 0.382683426f, 0.195090324f};
+    return mk(h ? C[q] : 1.0f, h ? -S[q] : 0.0f);
+}
 template <bool INV>
-PNP_HD void fft512_a2(c32 (&a)[16], const c32* tw, int h) {            // after it, before the butterfly
+PNP_HD void fft512_a2(c32 (&a)[16], int h) {                          // after it, before the butterfly
     dft16<INV>(a);
 #pragma unroll
-    for (int q = 1; q < 16; ++q) a[q] = tmul<INV>(a[q], tw[16 * q * h]);
+    for (int q = 1; q < 16; ++q) a[q] = tmul<INV>(a[q], w32_or_one(q, h));
 }
 // butterfly of lanes (k2,0),(k2,1): the h = 0 lane keeps the sum, the h = 1 lane the difference
 PNP_HD c32 bfly2(c32 own, c32 other, int h) { return h ? (other - own) : (own + other); }
 template <bool INV>
-PNP_HD void fft512_b1(c32 (&a)[16], const c32* tw, int h) {            // after the butterfly, before the exchange
+PNP_HD void fft512_b1(c32 (&a)[16], int h) {                          // after the butterfly, before the exchange
 #pragma unroll
-    for (int q = 1; q < 16; ++q) a[q] = tmul<INV>(a[q], tw[16 * q * h]);
+    for (int q = 1; q < 16; ++q) a[q] = tmul<INV>(a[q], w32_or_one(q, h));
     dft16<INV>(a);
 }
 template <bool INV>

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
         // structure B, inverse direction: k-layout -> t-layout
 #pragma unroll
         for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_quad_swap1(a[q].x), dpp_quad_swap1(a[q].y)), h);
-        fft512_b1<true>(a, twl, h);
+        fft512_b1<true>(a, h);
         xchg_k2t(a, region, t);
         fft512_b2<true>(a, twl, t);
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
         // structure A, forward direction: t-layout -> k-layout
         fft512_a1<false>(a, twl, t);
         xchg_t2k(a, region, t);
-        fft512_a2<false>(a, twl, h);
+        fft512_a2<false>(a, h);
 #pragma unroll
         for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_quad_swap1(a[q].x), dpp_quad_swap1(a[q].y)), h);
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ void col5_a(c32 (&a)[16], const c32* twl, c32* region
     const int h = t & 1;
     fft512_a1<INV>(a, twl, t);
     xchg_t2k(a, region, t);
-    fft512_a2<INV>(a, twl, h);
+    fft512_a2<INV>(a, h);
 #pragma unroll
     for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_row_ror8(a[q].x), dpp_row_ror8(a[q].y)), h);
 }
@@ -201,7 +201,7 @@ __device__ __forceinline__ void col5_b(c32 (&a)[16], const c32* twl, c32* region
     const int h = t & 1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_row_ror8(a[q].x), dpp_row_ror8(a[q].y)), h);
-    fft512_b1<INV>(a, twl, h);
+    fft512_b1<INV>(a, h);
     xchg_k2t(a, region, t);
     fft512_b2<INV>(a, twl, t);
 }

@@ -22,7 +22,7 @@ static void coop_a(std::vector<c32>& v, bool inv) {
         const int k2 = L >> 1, h = L & 1;
         c32 a[16];
         for (int i = 0; i < 16; ++i) a[i] = lds[k2 * 34 + 2 * i + h];
-        if (inv) fft512_a2<true>(a, TW, h); else fft512_a2<false>(a, TW, h);
+        if (inv) fft512_a2<true>(a, h); else fft512_a2<false>(a, h);
         for (int q = 0; q < 16; ++q) regs[L][q] = a[q];
     }
     for (int L = 0; L < 32; ++L) {
@@ -42,7 +42,7 @@ static void coop_b(std::vector<c32>& v, bool inv) {
         const int k2 = L >> 1, h = L & 1;
         c32 a[16];
         for (int q = 0; q < 16; ++q) a[q] = bfly2(regs[L][q], regs[L ^ 1][q], h);
-        if (inv) fft512_b1<true>(a, TW, h); else fft512_b1<false>(a, TW, h);
+        if (inv) fft512_b1<true>(a, h); else fft512_b1<false>(a, h);
         for (int i = 0; i < 16; ++i) lds[k2 * 34 + 2 * i + h] = a[i];
     }
     for (int t = 0; t < 32; ++t) {
