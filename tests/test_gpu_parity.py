@@ -2,7 +2,8 @@
 vectors from the unmodified reference.  Run on the MI355X box with `pytest -m gpu`.
 
 Tolerances (fp32 device arithmetic vs the float64 oracle):
-  * single transforms / operators : relative L2 <= 2e-6   (fp32 FFT round-off, 256..512 points)
+  * single transforms / operators : relative L2 <= 2e-6   (fp32 FFT round-off, 256..512 points);
+    one x-update from identical state (teacher-forced): <= 5e-7 (measured 1.6e-7 .. 2.0e-7)
   * whole solves, north-star bar   : relative L2 <= 1e-5 and |dPSNR| <= 0.01 dB
     -- holds for ADMM_L1 at any iteration count and for ADMM_CNC up to ~40 iterations; the
     committed CNC defaults (reo*lambda*b = 1.6 > 1) make the iteration map locally expansive, so
@@ -146,7 +147,7 @@ def test_dc_step_teacher_forced(P, torch, golden_inputs, H, W):
             for b in range(B):
                 ref = O.dc_step(z[b].astype(np.float64), w[b].astype(np.float64),
                                 ys[b].astype(np.complex64).astype(np.complex128), masks[mid[b]], 0.05)
-                assert rel_l2(x[b], ref) <= 2e-6, (fast, b)
+                assert rel_l2(x[b], ref) <= 5e-7, (fast, b)          # measured 1.6e-7 .. 2.0e-7
 
 
 def test_prox_kernels(P, torch):
@@ -284,7 +285,7 @@ def test_cnc_100_iterations_config2(P, golden_inputs, fast):
             for b in range(B):
                 xr, zr, wr = O.dc_step(z[b].astype(np.float64), w[b].astype(np.float64), y64[b], masks[0], 0.05), None, None
                 zr, wr = O.cnc_step(xr, z[b].astype(np.float64), w[b].astype(np.float64), 0.45, 0.5, 0.05, 64)
-                assert rel_l2(x1[b], xr) <= 2e-6 and rel_l2(z1[b], zr) <= 2e-6
+                assert rel_l2(x1[b], xr) <= 5e-7 and rel_l2(z1[b], zr) <= 2e-6
                 assert np.abs(w1[b] - wr).max() <= 2e-6
         eng.init_state()                                                   # (b)
         eng.admm_cnc(100, 0.45, 0.5, 0.05, 64)
