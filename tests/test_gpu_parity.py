@@ -615,3 +615,41 @@ def test_plain_c_consumer_runs_the_loop(P, tmp_path):
         x = eng.x()
     assert abs(float(x.astype(np.float64).sum()) - chk) <= 1e-6 * abs(chk)
     assert 'path fused' in out
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_randomized_configurations_vs_oracle(P, seed):
+    """Random batch sizes (odd ones included), random sampling densities and patterns, random
+    hyper-parameters and iteration counts, both solvers, fused and generic kernels, 256 and 512."""
+    rng = np.random.default_rng(1000 + seed)
+    H = 512 if seed % 4 == 3 else 256
+    B = int(rng.integers(1, 8))
+    K = int(rng.integers(1, 4))
+    masks = np.zeros((K, H, H), np.uint8)
+    for k in range(K):
+        dens = rng.uniform(0.05, 0.9)
+        if k % 2 == 0:
+            masks[k] = rng.uniform(size=(H, H)) < dens
+        else:
+            masks[k][rng.uniform(size=H) < dens, :] = 1            # whole rows (Cartesian-like)
+        masks[k][0, 0] = 1
+    mid = rng.integers(0, K, B).astype(np.int32)
+    ys = np.stack([O.synthetic_problem(int(rng.integers(0, 10000)), masks[mid[b]], H, H)[1] for b in range(B)]).astype(np.complex64)
+    iters = int(rng.integers(1, 9))
+    alpha, lam, reo = rng.uniform(0.2, 1.0), rng.uniform(0.05, 1.0), rng.uniform(0.01, 0.5)
+    b_ = float(rng.uniform(0.2, 1.6) / (reo * lam))        # reo*lambda*b <= 1.6 as in the committed presets: beyond that the
+                                                            # CNC map amplifies fp32 round-off by > 10x per iteration
+    fast = int(seed % 2)
+    with P.Engine(H, H, Bmax=B) as eng:
+        eng.set_fast_path(fast)
+        eng.upload(ys, masks, mid)
+        eng.init_state()
+        eng.admm_cnc(iters, alpha, lam, reo, b_)
+        xc = eng.x()
+        eng.init_state()
+        eng.admm_l1(iters, lam, reo)
+        xl = eng.x()
+    for b in range(B):
+        y128 = ys[b].astype(np.complex128)
+        assert rel_l2(xc[b], O.admm_cnc(y128, masks[mid[b]], iters, alpha, lam, reo, b_)) <= 1e-5, (seed, b)
+        assert rel_l2(xl[b], O.admm_l1(y128, masks[mid[b]], iters, lam, reo)) <= 1e-5, (seed, b)
