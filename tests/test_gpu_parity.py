@@ -653,3 +653,28 @@ def test_randomized_configurations_vs_oracle(P, seed):
         y128 = ys[b].astype(np.complex128)
         assert rel_l2(xc[b], O.admm_cnc(y128, masks[mid[b]], iters, alpha, lam, reo, b_)) <= 1e-5, (seed, b)
         assert rel_l2(xl[b], O.admm_l1(y128, masks[mid[b]], iters, lam, reo)) <= 1e-5, (seed, b)
+
+
+def test_integration_md_ctypes_stub_runs(golden_inputs, golden_admm, tmp_path):
+    """The ctypes stub printed in INTEGRATION.md section 2 (what a maintainer of the reference would
+    paste) is executed as written -- no package import, no torch -- and must reproduce the
+    reference's 50-iteration CNC result."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    code = re.findall(r"```python\n(import ctypes as C.*?)```", md, flags=re.S)[0]
+    code = code.replace("os.path.join(os.path.dirname(__file__), 'libpnpmri.so')",
+                        repr(os.path.join(ROOT, 'pnp_admm_cnc_mri_amd', 'libpnpmri.so')))
+    img = O.requantise(golden_inputs['gray'])[None]
+    np.savez(tmp_path / 'in.npz', img=img, mask=golden_inputs['masks']['Q_Random30'], noises=golden_inputs['noises'])
+    script = code + (
+        "\nimport sys\nd = np.load(sys.argv[1])\n"
+        "x = admm_cnc_loop(d['img'], d['mask'], d['noises'], 0.45, 50, 0.5, 0.05, 64)\n"
+        "np.save(sys.argv[2], x)\n")
+    (tmp_path / 'stub.py').write_text(script)
+    subprocess.check_call([sys.executable, str(tmp_path / 'stub.py'), str(tmp_path / 'in.npz'), str(tmp_path / 'x.npy')])
+    x = np.load(tmp_path / 'x.npy')
+    assert rel_l2(x[0], golden_admm['cnc_random30_it50']) <= 1e-4
