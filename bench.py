@@ -92,6 +92,43 @@ def cpu_baseline_all_cores(budget_s=8.0, iters=100):
                       % (cores, budget_s, iters, sum(n for n, _ in res), wall)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start the N rank processes as CHILDREN of this
+    process (which has not imported torch and never initialises HIP), one per GPU, with the
+    torch.distributed env of a one-node job on 127.0.0.1; relay rank 0's JSON line and return the
+    worst exit code.  No exec of an initialised process, no hop under a profiler."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        rc = 0
+        live = list(procs)
+        while live:                                      # a rank that dies takes the job down, not into a hang
+            time.sleep(0.05)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in live:
+                        q.terminate()
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -102,18 +139,22 @@ def main():
     ap.add_argument('--generic', action='store_true', help='force the generic (unfused) kernels')
     ap.add_argument('--size', type=int, default=256, choices=[256, 512],
                     help='slice edge; 512 = the shape of config 5 (seeded masks, mask_id = b %% 3), not the headline')
+    ap.add_argument('--precision', choices=['f32', 'f64'], default='f32',
+                    help="f64 = the double-precision engine (meets 1e-5 against the float64 reference at 100 CNC "
+                         "iterations, DESIGN.md section 2); the headline stays f32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--rehearse-gloo', action='store_true',
                     help='rehearsal of the N>1 launch path on a box with ONE GPU: gloo backend, all ranks on cuda:0')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))               # parent: never touches the GPU
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`' % (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
@@ -148,6 +189,14 @@ def main():
     if args.generic:
         eng.set_fast_path(0)
     eng.synthesize(img, noise, masks, mask_id)                        # y = fft2(img)*mask + noise, on device
+    if args.precision == 'f64':                                       # same measurements, double-precision engine
+        y32 = eng.download_y()
+        eng.close()
+        eng = P.Engine(H, W, Bmax=B, device=local_rank, precision='f64')
+        if args.generic:
+            eng.set_fast_path(0)
+        eng.upload(y32, masks, mask_id)
+        del y32
     eng.init_state()
 
     def run(n):
@@ -174,7 +223,7 @@ def main():
 
     # the one collective of the job: gather x on rank 0 over RCCL (timed apart from the steps)
     gather_ms = None
-    x_dev = torch.empty((B, H, W), dtype=torch.float32, device='cuda')
+    x_dev = torch.empty((B, H, W), dtype=torch.float64 if args.precision == 'f64' else torch.float32, device='cuda')
     eng.x(out=x_dev)
     eng.sync()
     if dist is not None:
@@ -200,37 +249,46 @@ def main():
         value = world * K / (wall_ms * 1e-3) * (B / B_PER_GPU)
         alg_bytes = ALG_BYTES_PER_PIXEL * H * W * B * K
         achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')        # per-iteration HBM bytes from rocprofv3 --pmc
+        # per-iteration HBM bytes of exactly this configuration from rocprofv3 --pmc (profiles/summarize.py)
+        traffic, traffic_src = None, None
+        tkey = '%s:%s:%d:%s:b%d' % (eng.path_name, args.solver, H, args.precision, B)
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(eng.path_name, {}).get('hbm_bytes_per_iteration_b512')
-                if traffic is not None and B != B_PER_GPU:
-                    traffic = None
+                ent = json.load(open(tpath)).get(tkey)
+                if ent:
+                    traffic, traffic_src = ent['hbm_bytes_per_iteration'], ent.get('from')
             except Exception:
                 traffic = None
+        sched = eng.schedule if eng.path_name == 'fused' else {'queues': 1, 'mixed': 0, 'chunk': 0}
+        ev_s_per_it = ev_ms * 1e-3 / K
         line = {
             'metric': 'ADMM iterations/sec on 256x256 complex64 slices (batch=512)',
             'value': value, 'unit': 'it/s (512-slice batches)',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'ADMM_%s, %d synthetic %dx%d complex64 slices per GPU, %s, S4:176 presets'
-                                   % (args.solver.upper(), B, H, W, 'Q_Random30' if H == 256 else 'seeded mask bank of 3'),
-                       'slices_per_gpu': B, 'path': eng.path_name,
+            'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'ADMM_%s, %d synthetic %dx%d complex64 slices per GPU, %s, %s presets'
+                                   % (args.solver.upper(), B, H, W, 'Q_Random30' if H == 256 else 'seeded mask bank of 3',
+                                      'S4:176' if args.solver == 'cnc' else 'S1:171'),
+                       'slices_per_gpu': B, 'path': eng.path_name, 'precision': args.precision,
                        'launches_per_iteration': eng.kernels_per_iteration,
-                       'queues': int(os.environ.get('PNP_FUSED_STREAMS', '2')) if eng.path_name == 'fused' else 1,
-                       'mixed_row_col_launches': (os.environ.get('PNP_FUSED_SCHED', '1') == '1') if eng.path_name == 'fused' else False},
+                       'queues': sched['queues'], 'mixed_row_col_launches': bool(sched['mixed'])},
             'slice_iterations_per_s': value * B_PER_GPU,
             'hip_event_ms_per_step': ev_ms / K,
             'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'note': 'achieved = 57*H*W*B algorithmic bytes per iteration / HIP-event time per iteration '
-                                 '(all launches of one iteration: 4 k_fmixed launches over 2 HIP queues whose heads and '
-                                 'tails overlap, so rocprof per-launch durations sum to ~1.1x this time; PNP_FUSED_STREAMS=1 '
-                                 'PNP_FUSED_SCHED=0 gives the sequential 2-kernel schedule, profiles/rocprof_*_sequential.json); '
-                                 'traffic = PMC-measured HBM bytes per iteration'},
+                         # the physically meaningful pair: bytes the kernels really move (PMC) over the same time
+                         'achieved_measured': None if traffic is None else traffic / ev_s_per_it / 1e9,
+                         'frac_measured': None if traffic is None else traffic / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
+                         'traffic_over_algorithmic': None if traffic is None else traffic / (alg_bytes / K),
+                         'traffic_from': traffic_src,
+                         'note': 'achieved = 57*H*W*B algorithmic bytes per iteration (SURVEY.md 8d: plain c2c float32 '
+                                 'formulation) / HIP-event time per iteration on the kernels\' stream; it exceeds the peak '
+                                 'because the fused kernels move fewer bytes than that formulation (two real slices per '
+                                 'complex FFT, Hermitian half plane, nibble masks).  achieved_measured / frac_measured = '
+                                 'PMC-measured HBM bytes per iteration (traffic, FETCH_SIZE x2 + WRITE_SIZE) / the same time.'},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)

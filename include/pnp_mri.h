@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   5
+#define PNP_ABI_VERSION   6
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -63,11 +63,14 @@ int pnp_set_fast_path(pnp_ctx* ctx, int enable);
  *   chunk           >0: run all iterations on `chunk` slices before the next chunk, one queue (default 0)
  * Environment defaults read at pnp_ctx_create: PNP_FUSED_STREAMS, PNP_FUSED_SCHED, PNP_FUSED_CHUNK. */
 int pnp_set_schedule(pnp_ctx* ctx, int queues, int mixed_launches, int chunk);
+/* the schedule in force (any pointer may be NULL) */
+int pnp_get_schedule(pnp_ctx* ctx, int* queues, int* mixed_launches, int* chunk);
 
 /* ---- problem upload ---------------------------------------------------------------------- */
 /* y: [B][H][W] complex64, the measurements  y = fft2(img)*mask + noises  (S4:102).
  * mask_bank: [K][H][W] uint8 in {0,1}, FFT-native layout (CS_MRI/Q_*.mat variable Q1; S4:185).
- * mask_id:   [B] int32 in [0,K): which mask each slice uses (NULL = all slices use mask 0).
+ * mask_id:   [B] int32 in [0,K): which mask each slice uses (NULL = all slices use mask 0);
+ *            validated for host and device inputs alike (PNP_E_ARG when out of range).
  * Replaces the per-image `y`, `index = np.nonzero(mask)` set-up of S4:101-106. */
 int pnp_upload_problem(pnp_ctx* ctx, const float* y, const uint8_t* mask_bank,
                        const int32_t* mask_id, int B, int K, int on_device);

@@ -130,6 +130,30 @@ def run_script(script, argv, logger_name):
     return g, cap.lines, out.getvalue()
 
 
+def check_cs_mri_views():
+    """The reference's CS_MRI/*.mat files through the product's loader (imageio.load_cs_mri, the
+    restatement of S4:182-191): Q1 equals the committed fixture, Q11 == fftshift(Q1),
+    OMEGA == MATLAB find(Q1) where the file has one; returns what was found, for known_answers.json."""
+    import scipy.io as sio
+    sys.path.insert(0, os.path.dirname(HERE))
+    from pnp_admm_cnc_mri_amd import imageio as IO
+    mask, noises = IO.load_cs_mri(os.path.join(REF, 'CS_MRI'), check=True)        # raises on any inconsistency
+    assert mask.dtype == np.float64 and mask.shape == (3, 256, 256)
+    assert noises.dtype == np.complex128 and noises.shape == (256, 256)
+    rec = {}
+    for k, name in enumerate(IO.MASK_NAMES):
+        d = sio.loadmat(os.path.join(REF, 'CS_MRI', name + '.mat'))
+        assert np.array_equal(mask[k], d['Q1'].astype(np.float64))
+        rec[name] = {'variables': sorted(v for v in d if not v.startswith('__')), 'sampled': int(mask[k].sum()),
+                     'Q11_is_fftshift_Q1': bool(np.array_equal(np.fft.fftshift(d['Q1']), d['Q11'])),
+                     'OMEGA_is_find_Q1': (bool(np.array_equal(d['OMEGA'].ravel(), np.flatnonzero(d['Q1'].T.ravel()) + 1))
+                                          if 'OMEGA' in d else None)}
+    raw = sio.loadmat(os.path.join(REF, 'CS_MRI', 'noises.mat'))['noises']
+    assert np.array_equal(noises, raw.astype(np.complex128) * 3.0)
+    rec['noises'] = {'dtype': str(raw.dtype), 'shape': list(raw.shape), 'scaled_by': 3.0}
+    return rec
+
+
 def main():
     cv2 = install_shims()
     os.makedirs(GOLD, exist_ok=True)
@@ -149,7 +173,18 @@ def main():
                         gray_u8=gray, noises_c128=noises,
                         **{k + '_packbits': v for k, v in masks.items()})
 
-    known = {'numpy': np.__version__, 'note': 'produced by oracle/make_golden.py from the unmodified reference scripts'}
+    cs_mri = check_cs_mri_views()
+    if '--inputs-only' in sys.argv:                      # refresh the input fixture + the .mat-view record only
+        kp = os.path.join(GOLD, 'known_answers.json')
+        known = json.load(open(kp))
+        known['cs_mri'] = cs_mri
+        with open(kp, 'w') as f:
+            json.dump(known, f, indent=1, sort_keys=True)
+        print(json.dumps(cs_mri, indent=1, sort_keys=True))
+        return
+
+    known = {'numpy': np.__version__, 'note': 'produced by oracle/make_golden.py from the unmodified reference scripts',
+             'cs_mri': cs_mri}
     arrays = {}
 
     # ---------------- ADMM_L1 (S1) and ADMM_CNC (S4), committed defaults, Q_Random30 ----------

@@ -34,7 +34,70 @@ SEEDS = {n: 1000 + i for i, n in enumerate(NAMES)}
 ITERS = 3
 
 
+def tiny_net(seed=5):
+    """3-layer 3x3 conv net (2 -> 8 -> 8 -> 1 channels, zero padding: border effects depend on where a
+    window sits) with NumPy-seeded weights; the split / augmentation goldens use it on both sides."""
+    rng = np.random.default_rng(seed)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 8, 3, 1, 1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, 1, 1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, 1, 1))
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.from_numpy(rng.standard_normal(tuple(p_.shape)).astype(np.float32) * 0.3))
+    return net.eval()
+
+
+def extra():
+    """Vectors added in round 2, appended to the existing fixture files (nothing else is regenerated):
+      * l1_d_drunet_gray_it9 -- S3 with --iter_num 9, so the x8 cycle visits all eight modes
+        including the 8 - i%8 inverses of modes 3 and 5 (S3:40-50);
+      * split_* / augment_* -- the reference's utils_model.test_split_fn (one- and two-level
+        splits) and utils_image.augment_img_tensor4 on small seeded inputs."""
+    MG.install_shims()
+    d = MG.scratch_dir()
+    os.chdir(d)
+    os.makedirs('model_zoo')
+    n = 'drunet_gray'
+    net, _, _ = D.build(n)
+    torch.save(D.seeded_state_dict(net, SEEDS[n]), os.path.join('model_zoo', n + '.pth'))
+    torch.set_num_threads(8)
+    npz = os.path.join(MG.GOLD, 'pnp_set1_05.npz')
+    arrays = dict(np.load(npz))
+    kj = os.path.join(MG.GOLD, 'pnp_known.json')
+    meta = json.load(open(kj))
+    known = meta['known']
+
+    g, lines, _ = MG.run_script(S3, ['--iter_num', '9'], 'Set1_dn_drunet_gray')
+    arrays['l1_d_drunet_gray_it9'] = np.asarray(g['out'][0], np.float32)
+    known['l1_d_drunet_gray_it9_opts'] = {k: float(v) for k, v in g['PNP_ADMM_L1_D_opts5'].items()}
+    known['l1_d_drunet_gray_it9_sum'] = float(arrays['l1_d_drunet_gray_it9'].astype(np.float64).sum())
+    known['l1_d_drunet_gray_it9_line'] = [l for l in lines if 'PSNR' in l and '05.png' in l][-1]
+
+    sys.path.insert(0, MG.REF)
+    from utils import utils_model as ref_um, utils_image as ref_ui
+    tn = tiny_net()
+    rng = np.random.default_rng(11)
+    with torch.no_grad():
+        for tag, shape, kw in (('split_1level', (2, 2, 40, 56), dict(refield=8, min_size=32, modulo=4)),
+                               ('split_2level', (1, 2, 80, 96), dict(refield=8, min_size=24, modulo=4)),
+                               ('split_whole_padded', (1, 2, 30, 27), dict(refield=8, min_size=32, modulo=4))):
+            L = torch.from_numpy(rng.random(shape, dtype=np.float32))
+            arrays[tag + '_in'] = L.numpy()
+            arrays[tag + '_out'] = ref_um.test_mode(tn, L, mode=2, sf=1, **kw).numpy()
+            known[tag + '_kw'] = kw
+        a = torch.arange(2 * 1 * 5 * 7, dtype=torch.float32).reshape(2, 1, 5, 7)
+        for m in range(8):
+            arrays['augment_mode%d' % m] = ref_ui.augment_img_tensor4(a, m).contiguous().numpy()
+    sys.path.remove(MG.REF)
+
+    np.savez_compressed(npz, **arrays)
+    with open(kj, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print({k: v.shape for k, v in arrays.items()})
+
+
 def main():
+    if '--extra' in sys.argv:
+        return extra()
     MG.install_shims()
     d = MG.scratch_dir()
     os.chdir(d)

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -29,6 +30,31 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess)                                                                      \
             return fail(PNP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// roctx ranges around the loops so that rocprofv3 --marker-trace output is self-describing.  The
+// marker library is looked up at run time (it is part of the ROCm image, not a link dependency);
+// without it the ranges are no-ops.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+struct Range {
+    static Roctx& api() { static Roctx r; return r; }
+    explicit Range(const char* name) { if (api().push) api().push(name); }
+    ~Range() { if (api().pop) api().pop(); }
+};
+}  // namespace
 
 struct pnp_ctx {
     int device = 0, H = 0, W = 0, Bmax = 0;
@@ -172,6 +198,13 @@ int pnp_ctx_destroy(pnp_ctx* c) {
 int pnp_set_stream(pnp_ctx* c, void* s) { CTX(c); c->stream = (hipStream_t)s; return PNP_OK; }
 int pnp_sync(pnp_ctx* c) { CTX(c); HIPCHK(hipStreamSynchronize(c->stream)); return PNP_OK; }
 int pnp_set_fast_path(pnp_ctx* c, int enable) { CTX(c); c->fast = enable != 0; return PNP_OK; }
+int pnp_get_schedule(pnp_ctx* c, int* queues, int* mixed_launches, int* chunk) {
+    CTX(c);
+    if (queues) *queues = c->sched.queues;
+    if (mixed_launches) *mixed_launches = c->sched.mixed;
+    if (chunk) *chunk = c->sched.chunk;
+    return PNP_OK;
+}
 int pnp_set_schedule(pnp_ctx* c, int queues, int mixed_launches, int chunk) {
     CTX(c);
     if (queues < 1 || queues > 4 || chunk < 0) return fail(PNP_E_ARG, "pnp_set_schedule: queues in 1..4, chunk >= 0");
@@ -202,7 +235,17 @@ static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_i
     int rc = copy_in(c, c->mask_bank, mask_bank, (size_t)K * c->N, on_device);
     if (rc) return rc;
     if (mask_id) {
-        if (!on_device) for (int i = 0; i < B; ++i) if (mask_id[i] < 0 || mask_id[i] >= K) return fail(PNP_E_ARG, "mask_id[%d]=%d out of range [0,%d)", i, mask_id[i], K);
+        // ids index the mask bank inside the kernels: validate them for host AND device inputs
+        // (B int32 values; a device array is read back once -- problem upload is not the hot path)
+        std::vector<int32_t> tmp;
+        const int32_t* ids = mask_id;
+        if (on_device) {
+            tmp.resize((size_t)B);
+            HIPCHK(hipMemcpyAsync(tmp.data(), mask_id, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            ids = tmp.data();
+        }
+        for (int i = 0; i < B; ++i) if (ids[i] < 0 || ids[i] >= K) return fail(PNP_E_ARG, "mask_id[%d]=%d out of range [0,%d)", i, ids[i], K);
         rc = copy_in(c, c->mask_id, mask_id, (size_t)B * sizeof(int32_t), on_device);
         if (rc) return rc;
     } else {
@@ -246,12 +289,14 @@ int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int
     if (!on_device) {
         const size_t need = img_bytes + noise_bytes;
         if (need > c->stage_bytes) {
+            c->B = 0;                                   // no valid problem until y has been rebuilt
             if (c->stage) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
             HIPCHK(hipMalloc(&c->stage, need));
+            c->B = B;
             c->stage_bytes = need;
         }
-        rc = copy_in(c, c->stage, img, img_bytes, 0); if (rc) return rc;
-        rc = copy_in(c, (char*)c->stage + img_bytes, noise, noise_bytes, 0); if (rc) return rc;
+        rc = copy_in(c, c->stage, img, img_bytes, 0); if (rc) { c->B = 0; return rc; }
+        rc = copy_in(c, (char*)c->stage + img_bytes, noise, noise_bytes, 0); if (rc) { c->B = 0; return rc; }
         d_img = (const float*)c->stage;
         d_noise = (const float2*)((char*)c->stage + img_bytes);
     }
@@ -371,6 +416,7 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, doubl
 
 int pnp_admm_l1_run(pnp_ctx* c, int iters, double lambda1, double reo) {
     CTX(c); NEED_PROBLEM(c);
+    Range r("pnp_admm_l1_run");
     if (c->f64) {
         if (iters < 0 || !(reo > 0.0)) return fail(PNP_E_ARG, "pnp_admm_l1_run: iters >= 0 and reo > 0 required");
         ProxParamsT<double> p{}; p.thr = reo * lambda1;
@@ -381,6 +427,7 @@ int pnp_admm_l1_run(pnp_ctx* c, int iters, double lambda1, double reo) {
 
 int pnp_admm_cnc_run(pnp_ctx* c, int iters, double alpha, double lambda1, double reo, double b) {
     CTX(c); NEED_PROBLEM(c);
+    Range r("pnp_admm_cnc_run");
     if (!(b > 0.0)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: b must be > 0");
     if (c->f64) {
         if (iters < 0 || !(reo > 0.0)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: iters >= 0 and reo > 0 required");
@@ -400,6 +447,7 @@ int pnp_download_x(pnp_ctx* c, float* x, int on_device) {
 
 int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo) {
     CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
+    Range r("pnp_dc_step");
     if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
     if (use_fused(c)) {

@@ -12,7 +12,7 @@
 // a pointwise stage and an inverse transform with no re-ordering in between.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PNP_HD __host__ __device__ __forceinline__
 #else
 #define PNP_HD inline

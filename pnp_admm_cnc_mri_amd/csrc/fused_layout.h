@@ -44,7 +44,8 @@ PNP_HD void hermitian_entry(const c32* y, const uint8_t* mask, int k1, int k2, c
     const int i2 = ((F_N - k1) & 255) * F_N + ((F_N - k2) & 255);
     const int m1 = mask[i1] != 0, m2 = mask[i2] != 0;
     const c32 y1 = y[i1], y2 = y[i2];
-    yh = mk(0.5f * ((float)m1 * y1.x + (float)m2 * y2.x), 0.5f * ((float)m1 * y1.y - (float)m2 * y2.y));
+    // select, do not multiply: an unsampled y entry (possibly NaN/Inf in user data) must not reach the result
+    yh = mk(0.5f * ((m1 ? y1.x : 0.0f) + (m2 ? y2.x : 0.0f)), 0.5f * ((m1 ? y1.y : 0.0f) - (m2 ? y2.y : 0.0f)));
     code = m1 + m2;
 }
 
@@ -78,7 +79,8 @@ PNP_HD void hermitian_entry512(const c32* y, const uint8_t* mask, int k1, int k2
     const int i2 = ((F5_N - k1) & 511) * F5_N + ((F5_N - k2) & 511);
     const int m1 = mask[i1] != 0, m2 = mask[i2] != 0;
     const c32 y1 = y[i1], y2 = y[i2];
-    yh = mk(0.5f * ((float)m1 * y1.x + (float)m2 * y2.x), 0.5f * ((float)m1 * y1.y - (float)m2 * y2.y));
+    // select, do not multiply: an unsampled y entry (possibly NaN/Inf in user data) must not reach the result
+    yh = mk(0.5f * ((m1 ? y1.x : 0.0f) + (m2 ? y2.x : 0.0f)), 0.5f * ((m1 ? y1.y : 0.0f) - (m2 ? y2.y : 0.0f)));
     code = m1 + m2;
 }
 

@@ -173,50 +173,54 @@ def seeded_state_dict(module, seed=0, gain=1.0):
 # ----------------------------------------------------------------------------------------------
 # inference helpers
 # ----------------------------------------------------------------------------------------------
+# The eight symmetries of the square as (quarter turns counter-clockwise in the (H, W) plane, then
+# an up-down flip), numbered the way utils/utils_image.py:333-349 numbers its x8 self-ensemble modes.
+_D4 = ((0, False), (1, True), (0, True), (3, False), (2, True), (1, False), (2, False), (3, True))
+
+
 def augment_img_tensor4(img, mode=0):
-    """utils/utils_image.py:333-349."""
-    if mode == 0:
-        return img
-    if mode == 1:
-        return img.rot90(1, [2, 3]).flip([2])
-    if mode == 2:
-        return img.flip([2])
-    if mode == 3:
-        return img.rot90(3, [2, 3])
-    if mode == 4:
-        return img.rot90(2, [2, 3]).flip([2])
-    if mode == 5:
-        return img.rot90(1, [2, 3])
-    if mode == 6:
-        return img.rot90(2, [2, 3])
-    if mode == 7:
-        return img.rot90(3, [2, 3]).flip([2])
-    raise ValueError(mode)
+    """x8 self-ensemble view `mode` of a [B,C,H,W] tensor (same numbering as the reference's
+    `augment_img_tensor4`; modes 3 and 5 are each other's inverse, every other mode is its own)."""
+    turns, flip = _D4[mode]
+    out = torch.rot90(img, turns, (2, 3)) if turns else img
+    return out.flip(2) if flip else out
+
+
+def _corner_span(n, refield):
+    """Length of the two overlapping windows [0, q) and [n - q, n) a side of length n is cut into:
+    half the side rounded up to the next multiple of the receptive field (utils_model.py:91-94)."""
+    return (n // 2 // refield + 1) * refield
 
 
 def test_split_fn(model, L, refield=32, min_size=256, sf=1, modulo=1):
-    """utils/utils_model.py:76-109: whole image when h*w <= min_size^2 (padded to `modulo`),
-    otherwise four overlapping quadrants stitched back (recursively beyond 4*min_size^2)."""
+    """Quadrant inference with the arithmetic of utils/utils_model.py:76-109, batched: an image of
+    at most min_size^2 pixels goes through the model whole (replicate-padded to a multiple of
+    `modulo`); a larger one is cut into its four overlapping corner windows, which are stacked into
+    ONE [4B, C, qh, qw] batch and sent through the model in one call (again split when a window is
+    itself larger than min_size^2), and each window contributes the quarter of the output it covers
+    without overlap.  One larger MIOpen launch per layer instead of four."""
+    B = L.shape[0]
     h, w = L.shape[-2:]
     if h * w <= min_size ** 2:
-        L = F.pad(L, (0, int(math.ceil(w / modulo) * modulo - w), 0, int(math.ceil(h / modulo) * modulo - h)), mode='replicate')
+        ph, pw = -h % modulo, -w % modulo
+        if ph or pw:
+            L = F.pad(L, (0, pw, 0, ph), mode='replicate')
         return model(L)[..., :h * sf, :w * sf]
-    top = slice(0, (h // 2 // refield + 1) * refield)
-    bottom = slice(h - (h // 2 // refield + 1) * refield, h)
-    left = slice(0, (w // 2 // refield + 1) * refield)
-    right = slice(w - (w // 2 // refield + 1) * refield, w)
-    Ls = [L[..., top, left], L[..., top, right], L[..., bottom, left], L[..., bottom, right]]
-    if h * w <= 4 * (min_size ** 2):
-        Es = [model(Ls[i].contiguous()) for i in range(4)]
+    qh, qw = _corner_span(h, refield), _corner_span(w, refield)
+    corners = [(r0, c0) for r0 in (0, h - qh) for c0 in (0, w - qw)]        # TL, TR, BL, BR
+    tiles = torch.cat([L[..., r0:r0 + qh, c0:c0 + qw] for r0, c0 in corners], dim=0).contiguous()
+    if h * w <= 4 * min_size ** 2:
+        E = model(tiles)
     else:
-        Es = [test_split_fn(model, Ls[i], refield, min_size, sf, modulo) for i in range(4)]
-    b, c = Es[0].shape[:2]
-    E = torch.zeros(b, c, sf * h, sf * w, dtype=L.dtype, device=L.device)
-    E[..., :h // 2 * sf, :w // 2 * sf] = Es[0][..., :h // 2 * sf, :w // 2 * sf]
-    E[..., :h // 2 * sf, w // 2 * sf:w * sf] = Es[1][..., :h // 2 * sf, (-w + w // 2) * sf:]
-    E[..., h // 2 * sf:h * sf, :w // 2 * sf] = Es[2][..., (-h + h // 2) * sf:, :w // 2 * sf]
-    E[..., h // 2 * sf:h * sf, w // 2 * sf:w * sf] = Es[3][..., (-h + h // 2) * sf:, (-w + w // 2) * sf:]
-    return E
+        E = test_split_fn(model, tiles, refield, min_size, sf, modulo)
+    out = torch.empty((B, E.shape[1], h * sf, w * sf), dtype=E.dtype, device=E.device)
+    hm, wm = (h // 2) * sf, (w // 2) * sf                                   # where the quarters meet
+    for k, (r0, c0) in enumerate(corners):
+        rows = slice(0, hm) if r0 == 0 else slice(hm, h * sf)               # output rows of this quarter
+        cols = slice(0, wm) if c0 == 0 else slice(wm, w * sf)
+        e = E[k * B:(k + 1) * B]
+        out[..., rows, cols] = e[..., rows.start - r0 * sf:rows.stop - r0 * sf, cols.start - c0 * sf:cols.stop - c0 * sf]
+    return out
 
 
 def test_mode(model, L, mode=0, refield=32, min_size=256, sf=1, modulo=1):

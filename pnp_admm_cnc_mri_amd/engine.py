@@ -78,6 +78,12 @@ class Engine:
         _lib.check(self._L.pnp_set_schedule(self._ctx, int(queues), 1 if mixed_launches else 0, int(chunk)))
 
     @property
+    def schedule(self):
+        q, m, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self._L.pnp_get_schedule(self._ctx, C.byref(q), C.byref(m), C.byref(ch)))
+        return {'queues': q.value, 'mixed': m.value, 'chunk': ch.value}
+
+    @property
     def path_name(self):
         return self._L.pnp_path_name(self._ctx).decode()
 
@@ -152,10 +158,16 @@ class Engine:
         fn = self._L.pnp_set_state_f64 if self.f64 else self._L.pnp_set_state
         _lib.check(fn(self._ctx, _ptr(zz), _ptr(ww), dev))
 
-    def get_state(self):
+    def get_state(self, z_out=None, w_out=None):
+        """-> (z, w) as host arrays, or copied device-to-device into the given device tensors."""
+        fn = self._L.pnp_get_state_f64 if self.f64 else self._L.pnp_get_state
+        if z_out is not None or w_out is not None:
+            if not all(o is None or _is_dev(o) for o in (z_out, w_out)):
+                raise TypeError('get_state outputs must be device tensors')
+            _lib.check(fn(self._ctx, _ptr(z_out), _ptr(w_out), 1))
+            return z_out, w_out
         z = np.empty((self.B, self.H, self.W), self._real)
         w = np.empty_like(z)
-        fn = self._L.pnp_get_state_f64 if self.f64 else self._L.pnp_get_state
         _lib.check(fn(self._ctx, _ptr(z), _ptr(w), 0))
         return z, w
 
@@ -167,11 +179,11 @@ class Engine:
         _lib.check(self._L.pnp_admm_cnc_run(self._ctx, int(iters), float(alpha), float(lambda1), float(reo), float(b)))
 
     def x(self, out=None):
+        fn = self._L.pnp_download_x_f64 if self.f64 else self._L.pnp_download_x
         if out is not None and _is_dev(out):
-            _lib.check(self._L.pnp_download_x(self._ctx, _ptr(out), 1))
+            _lib.check(fn(self._ctx, _ptr(out), 1))
             return out
         x = np.empty((self.B, self.H, self.W), self._real)
-        fn = self._L.pnp_download_x_f64 if self.f64 else self._L.pnp_download_x
         _lib.check(fn(self._ctx, _ptr(x), 0))
         return x
 

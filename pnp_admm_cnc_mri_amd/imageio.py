@@ -63,11 +63,50 @@ def requantise(img_uint8):
     return uint2single(single2uint(uint2single(np.asarray(img_uint8))))
 
 
-def load_cs_mri(root='CS_MRI'):
-    """-> (mask [3,256,256] float64 for Q_Random30/Q_Radial30/Q_Cartesian30, noises complex128*3.0)
-    exactly as S4:182-191 builds them."""
+MASK_NAMES = ['Q_Random30', 'Q_Radial30', 'Q_Cartesian30']
+
+
+def load_mask_mat(path, check=True):
+    """One CS_MRI/Q_*.mat sampling pattern -> float64 [H,W] 0/1 mask in un-shifted FFT layout
+    (what S4:185 takes as `Q1`).  The files carry up to three views of the same pattern:
+        Q1     uint8 [H,W], un-shifted (DC at [0,0])       -- the one the solvers read
+        Q11    uint8 [H,W] = fftshift(Q1) (DC centred)     -- for display
+        OMEGA  int32 [n,1], MATLAB find(Q1): 1-based column-major indices, ascending (absent for radial)
+    Q1 is used when present; a file holding only Q11 or OMEGA (+ a square size inferred from the
+    largest index is NOT attempted: pass Q1/Q11) is converted.  With check=True the views that are
+    present must agree, otherwise ValueError."""
     import scipy.io as sio
-    names = ['Q_Random30', 'Q_Radial30', 'Q_Cartesian30']
-    mask = np.array([sio.loadmat(os.path.join(root, n + '.mat')).get('Q1').astype(np.float64) for n in names])
+    d = sio.loadmat(path)
+    q1, q11, om = d.get('Q1'), d.get('Q11'), d.get('OMEGA')
+    if q1 is None and q11 is None:
+        raise ValueError('%s holds neither Q1 nor Q11' % path)
+    if q1 is None:
+        q1 = np.fft.ifftshift(np.asarray(q11))
+    q1 = (np.asarray(q1) != 0)
+    if check:
+        if q11 is not None and not np.array_equal(np.fft.fftshift(q1), np.asarray(q11) != 0):
+            raise ValueError('%s: Q11 is not fftshift(Q1)' % path)
+        if om is not None:
+            want = np.flatnonzero(q1.T.ravel()) + 1                   # MATLAB find(): column-major, 1-based
+            if not np.array_equal(np.asarray(om).ravel().astype(np.int64), want):
+                raise ValueError('%s: OMEGA is not find(Q1)' % path)
+    return q1.astype(np.float64)
+
+
+def load_cs_mri(root='CS_MRI', check=True):
+    """-> (mask [3,256,256] float64 for Q_Random30/Q_Radial30/Q_Cartesian30, noises complex128*3.0)
+    exactly as S4:182-191 builds them (Q1 as float64; k-space noise scaled by 3.0)."""
+    import scipy.io as sio
+    mask = np.array([load_mask_mat(os.path.join(root, n + '.mat'), check) for n in MASK_NAMES])
     noises = sio.loadmat(os.path.join(root, 'noises.mat')).get('noises').astype(np.complex128) * 3.0
     return mask, noises
+
+
+def save_mask_mat(path, q1, with_omega=True):
+    """Write a sampling pattern in the reference's .mat layout (Q1, Q11, OMEGA)."""
+    import scipy.io as sio
+    q1 = (np.asarray(q1) != 0).astype(np.uint8)
+    d = {'Q1': q1, 'Q11': np.fft.fftshift(q1)}
+    if with_omega:
+        d['OMEGA'] = (np.flatnonzero(q1.T.ravel()) + 1).astype(np.int32)[:, None]
+    sio.savemat(path, d, do_compression=True)

@@ -33,7 +33,9 @@ def gather_slices(x_local, B_total, dst=0, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)                       # position inside `group`: which shard this rank holds
+    # `dst` is a GLOBAL rank (what dist.gather takes), so compare it with the global rank
+    is_dst = dist.get_rank() == dst
     sizes = shard_sizes(B_total, world)
     if x_local.shape[0] != sizes[rank]:
         raise ValueError('rank %d holds %d slices, expected %d' % (rank, x_local.shape[0], sizes[rank]))
@@ -43,9 +45,9 @@ def gather_slices(x_local, B_total, dst=0, group=None):
         pad = torch.zeros((bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         pad[:send.shape[0]] = send
         send = pad
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    bufs = [torch.empty_like(send) for _ in range(world)] if is_dst else None
     dist.gather(send, bufs, dst=dst, group=group)
-    if rank != dst:
+    if not is_dst:
         return None
     return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
 
@@ -89,6 +91,8 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
         kw['y'] = np.asarray(y)[lo:hi]
     if mask_id is not None:
         kw['mask_id'] = np.asarray(mask_id)[lo:hi]
+    if noises is not None and np.ndim(noises) == 3:       # per-slice k-space noise [B,H,W]: shard it with the slices
+        noises = np.asarray(noises)[lo:hi]
     if hi > lo:
         res = solver(mask, noises, **kw)
         out = res[0] if isinstance(res, tuple) else res

@@ -23,7 +23,6 @@ from collections import OrderedDict
 import numpy as np
 
 from . import imageio
-from . import metrics as _metrics
 from .engine import Engine
 
 # CLI presets of the reference scripts (positional order differs per script!)
@@ -34,17 +33,25 @@ PRESETS = {
 
 
 def logger_info(logger_name, log_path):
-    """File + stream logger with the reference's format (utils/utils_logger.py:25-44)."""
+    """File + stream logger with the reference's format (utils/utils_logger.py:25-44).  Like the
+    reference, one logger per name for the whole process; unlike it, a later call with another
+    `log_path` moves the file handler there instead of silently logging into the first file."""
     log = logging.getLogger(logger_name)
-    if not log.handlers:
-        formatter = logging.Formatter('%(asctime)s.%(msecs)03d : %(message)s', datefmt='%y-%m-%d %H:%M:%S')
+    formatter = logging.Formatter('%(asctime)s.%(msecs)03d : %(message)s', datefmt='%y-%m-%d %H:%M:%S')
+    want = os.path.abspath(log_path)
+    files = [h for h in log.handlers if isinstance(h, logging.FileHandler)]
+    if not any(h.baseFilename == want for h in files):
+        for h in files:
+            log.removeHandler(h)
+            h.close()
         fh = logging.FileHandler(log_path, mode='a')
         fh.setFormatter(formatter)
-        log.setLevel(logging.INFO)
         log.addHandler(fh)
+    if not any(type(h) is logging.StreamHandler for h in log.handlers):
         sh = logging.StreamHandler()
         sh.setFormatter(formatter)
         log.addHandler(sh)
+    log.setLevel(logging.INFO)
     return log
 
 
@@ -53,8 +60,10 @@ class _Job:
     inputs (S4:83-109), outputs and metrics (S4:138-172)."""
 
     def __init__(self, mask, noises, tag, suffix, images=None, y=None, mask_id=None, testsets='testsets',
-                 testset_name='Set1', results='results', save_E=None, device=0, log=None, ssim=None):
-        self.tag, self.suffix = tag, suffix
+                 testset_name='Set1', results='results', save_E=None, device=0, log=None, ssim=None,
+                 psnr_fmt='{:.4f}'):
+        # psnr_fmt: S1:150 and S3:320 print the per-image PSNR with two decimals, S4:155 / S6:332 / S6:548 with four
+        self.tag, self.suffix, self.psnr_fmt = tag, suffix, psnr_fmt
         mask = np.asarray(mask)
         self.mask_bank = mask[None] if mask.ndim == 2 else mask
         self.H, self.W = self.mask_bank.shape[1:]
@@ -101,8 +110,12 @@ class _Job:
             self.log.info(os.path.join(testsets, testset_name))
         self.testset_name = testset_name
 
-    def open_engine(self):
+    def open_engine(self, stream=None):
+        """stream: HIP stream handle every engine call is ordered on (PnP: torch's current stream),
+        set BEFORE the first kernel so upload / synthesis / init and the loop share one queue."""
         eng = Engine(self.H, self.W, Bmax=self.B, device=self.device)
+        if stream is not None:
+            eng.set_stream(stream)
         if self.y is not None:
             eng.upload(self.y, self.mask_bank, self.mask_id)
         else:
@@ -127,7 +140,7 @@ class _Job:
             for n in range(self.B):
                 psnr1[n] = info['psnr'][n]
                 if self.log is not None and self.names is not None:
-                    self.log.info('{:s} - PSNR: {:.4f} dB; SSIM: {:.4f} ; RE: {:.4f}.'.format(
+                    self.log.info(('{:s} - PSNR: ' + self.psnr_fmt + ' dB; SSIM: {:.4f} ; RE: {:.4f}.').format(
                         self.names[n], info['psnr'][n], info['ssim'][n] if self.ssim else float('nan'), info['re'][n]))
             if self.log is not None:
                 ave = lambda v: sum(v) / len(v) if v else float('nan')
@@ -142,16 +155,25 @@ class _Job:
         return out, psnr1, info
 
 
+def _result(eng, iter_num):
+    """x of the last iteration; with iter_num = 0 the loop body never runs and the reference returns
+    its initial x = |ifft2(y)| (S4:103, 138), which is the engine's z0."""
+    if iter_num <= 0:
+        return eng.get_state()[0]
+    return eng.x()
+
+
 def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets', testset_name='Set1',
             results='results', save_E=None, device=0, return_info=False, **ADMM_L1_opts):
     """ADMM with L1 prox on the MI355X engine.  Reference: "【1】ADMM_L1.py":29-169."""
     iter_num = ADMM_L1_opts.get('iter_num', 20)          # S1:35
     lambda1 = ADMM_L1_opts.get('lambda1', 0.04)          # S1:36
     reo = ADMM_L1_opts.get('reo', 0.04)                  # S1:37
-    job = _Job(mask, noises, 'ADMM_L1', '_PDG L1', images, y, mask_id, testsets, testset_name, results, save_E, device)
+    job = _Job(mask, noises, 'ADMM_L1', '_PDG L1', images, y, mask_id, testsets, testset_name, results, save_E, device,
+               psnr_fmt='{:.2f}')                        # S1:150
     with job.open_engine() as eng:
         eng.admm_l1(iter_num, lambda1, reo)              # S1:111-126, all slices, on device
-        x = eng.x()
+        x = _result(eng, iter_num)
         out, _, info = job.finish(eng, x)
     return (out, info) if return_info else out
 
@@ -167,6 +189,6 @@ def ADMM_CNC(mask, noises, images=None, y=None, mask_id=None, testsets='testsets
     job = _Job(mask, noises, 'ADMM_CNC', '_ADMM CNC', images, y, mask_id, testsets, testset_name, results, save_E, device)
     with job.open_engine() as eng:
         eng.admm_cnc(iter_num, alpha, lambda1, reo, b)   # S4:115-132
-        x = eng.x()
+        x = _result(eng, iter_num)
         out, _, info = job.finish(eng, x)
     return (out, info) if return_info else out

@@ -74,10 +74,12 @@ def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, d
 
 
 def _device_state(torch, eng, B, H, W, dev):
-    z0, w0 = eng.get_state()                           # z0 = |ifft2(y)|, w0 = 0 (S6:253-256)
-    z = torch.from_numpy(z0).to(dev).reshape(B, 1, H, W).contiguous()
-    w = torch.from_numpy(w0).to(dev).reshape(B, 1, H, W).contiguous()
-    x = torch.empty_like(z)
+    """z0 = |ifft2(y)|, w0 = 0 (S6:253-256) copied device-to-device into torch tensors; x starts as
+    z0 too (S6:252-253), which is what a zero-iteration call returns."""
+    z = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    w = torch.empty_like(z)
+    eng.get_state(z, w)
+    x = z.clone()
     return x, z, w
 
 
@@ -102,8 +104,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
     job = _Job(mask, noises, model_name, 'PNP_ADMM_CNC_D', images, y, mask_id, testsets, testset_name, results,
                save_E, device)
     den = _load_model(model_name, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)   # x8 = False, S6:93
-    with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
-        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
         s = torch.empty_like(z)
@@ -143,8 +144,7 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
         den2 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)
     else:
         den2 = _load_model(model_name2, model2, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype)
-    with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
-        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
         s, t, z_new = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
@@ -170,11 +170,10 @@ def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, t
     dev = torch.device('cuda', device)
     fam = D.family(model_name)
     x8 = fam in ('drunet', 'ffdnet')                       # x8 = True (S3:87) survives only there (S3:130,142,181)
-    job = _Job(mask, noises, model_name, 'PNP_ADMM_L1_D', images, y, mask_id, testsets, testset_name, results,
-               save_E, device)
+    job = _Job(mask, noises, model_name, '_' + model_name + '_PNP_ADMM_L1_D', images, y, mask_id, testsets,
+               testset_name, results, save_E, device, psnr_fmt='{:.2f}')            # file name S3:308, PSNR format S3:320
     den = _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, dev, cnn_dtype)
-    with torch.cuda.device(dev), torch.no_grad(), job.open_engine() as eng:
-        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
         t = torch.empty_like(z)

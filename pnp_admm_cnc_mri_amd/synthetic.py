@@ -77,12 +77,11 @@ _MASK_FIXTURE = None
 
 def reference_masks():
     """The reference's three 256x256 sampling patterns (CS_MRI/Q_{Random,Radial,Cartesian}30.mat,
-    variable Q1), shipped bit-packed as data in tests/golden/inputs_set1_05.npz."""
+    variable Q1) as package data, bit-packed (pnp_admm_cnc_mri_amd/data/cs_mri_masks.npz, 8 KiB each)."""
     global _MASK_FIXTURE
     if _MASK_FIXTURE is None:
         import os
-        p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'inputs_set1_05.npz')
-        d = np.load(p)
+        d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'cs_mri_masks.npz'))
         _MASK_FIXTURE = {k[:-len('_packbits')]: np.unpackbits(d[k])[:65536].reshape(256, 256)
                          for k in d.files if k.endswith('_packbits')}
     return _MASK_FIXTURE

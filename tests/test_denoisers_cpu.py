@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLD
@@ -73,3 +74,56 @@ def test_ircnn_bank_index():
     den = D.Denoiser('ircnn_gray', D.build('ircnn_gray')[0], 15 / 255.0, sigmas=sig, bank=None)
     assert [int(np.ceil(float(s) * 255. / 2.) - 1) for s in sig] == [24, 15, 7]
     den.select_bank(0)       # no bank: no-op
+
+
+def _tiny_net(seed=5):
+    """the 3-layer conv net of oracle/make_golden_pnp.py::tiny_net (same NumPy-seeded weights)"""
+    rng = np.random.default_rng(seed)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 8, 3, 1, 1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, 1, 1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, 1, 1))
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.from_numpy(rng.standard_normal(tuple(p_.shape)).astype(np.float32) * 0.3))
+    return net.eval()
+
+
+@pytest.fixture(scope='module')
+def pnp_golden():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    import json
+    return (np.load(os.path.join(here, 'golden', 'pnp_set1_05.npz')),
+            json.load(open(os.path.join(here, 'golden', 'pnp_known.json')))['known'])
+
+
+@pytest.mark.parametrize('tag', ['split_1level', 'split_2level', 'split_whole_padded'])
+def test_split_fn_matches_the_reference(pnp_golden, tag):
+    """The batched quadrant forward against outputs of the reference's utils_model.test_mode(mode=2)
+    (utils/utils_model.py:76-109) on the same seeded conv net, whose zero padding makes every output
+    pixel depend on which window produced it: one-level split, recursive split, padded whole image."""
+    arrays, known = pnp_golden
+    net = _tiny_net()
+    calls = []
+    model = lambda t: (calls.append(tuple(t.shape)), net(t))[1]
+    with torch.no_grad():
+        got = D.test_mode(model, torch.from_numpy(arrays[tag + '_in']), mode=2, sf=1, **known[tag + '_kw'])
+    want = arrays[tag + '_out']
+    assert got.shape == want.shape
+    # batched vs per-window conv calls differ in summation order (~2e-6 on O(1) values); a misplaced window is O(1)
+    assert np.abs(got.numpy() - want).max() <= 1e-5, np.abs(got.numpy() - want).max()
+    B = arrays[tag + '_in'].shape[0]
+    if tag == 'split_1level':
+        assert calls == [(4 * B, 2, 24, 32)]              # the four windows in ONE model call
+    elif tag == 'split_2level':
+        assert calls == [(64 * B, 2, 24, 24)]             # 80x96 -> 48x56 -> 32x32 -> 24x24 windows: 4^3 of them, still one call
+    else:
+        assert calls == [(B, 2, 32, 28)]                  # whole image, replicate-padded to modulo 4
+
+
+def test_augment_modes_match_the_reference(pnp_golden):
+    """all eight x8 views against the reference's augment_img_tensor4 (utils/utils_image.py:333-349)
+    on a non-square tensor (shape changes for the odd quarter turns)."""
+    arrays, _ = pnp_golden
+    a = torch.arange(2 * 1 * 5 * 7, dtype=torch.float32).reshape(2, 1, 5, 7)
+    for m in range(8):
+        assert np.array_equal(D.augment_img_tensor4(a, m).numpy(), arrays['augment_mode%d' % m]), m

@@ -1,0 +1,316 @@
+"""GPU tests added in round 2: the self-launching multi-GPU bench, the reference's file names / log
+formats for every solver, the .mat input path, zero-iteration calls, unsampled NaNs, device-side
+argument validation, and the PnP coverage holes (IRCNN bank, all eight x8 modes, full-batch config 3)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import admm_oracle as O
+from conftest import rel_l2, GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import solvers_pnp, denoisers, _lib
+    assert _lib.device_count() >= 1 and torch.cuda.is_available()
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
+    known = json.load(open(os.path.join(GOLD, 'pnp_known.json')))
+    gold = np.load(os.path.join(GOLD, 'pnp_set1_05.npz'))
+    return dict(torch=torch, P=P, S=solvers_pnp, D=denoisers, known=known['known'], gold=gold)
+
+
+# ----------------------------------------------------------------------------------------------
+# bench.py launches its own ranks
+# ----------------------------------------------------------------------------------------------
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts two rank processes as
+    children (both on this box's one GPU, gloo rendezvous: --rehearse-gloo), relays rank 0's single
+    JSON line and exits 0.  The N = 1 invocation keeps its shape."""
+    env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse-gloo', '--batch', '32', '--steps', '3',
+           '--warmup', '1']
+    r = subprocess.run(cmd, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == 'weak' and j['x_finite']
+    assert j['gather_ms'] is not None and j['cpu_baseline'] is None
+    assert j['value'] > 0 and abs(j['value'] - 2 * 3 / (j['ms_per_step'] * 3e-3) * 32 / 512) <= 1e-6 * j['value']
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '32', '--steps', '3', '--warmup', '1',
+                         '--no-cpu-baseline'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r1.returncode == 0, r1.stderr.decode()[-2000:]
+    j1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert j1['n_gpus'] == 1 and j1['gather_ms'] is None and set(j1['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    # same slices on rank 0 of both runs: the N = 2 job's rank 0 did exactly the N = 1 job's work
+    assert j1['x_checksum'] == j['x_checksum']
+
+
+# ----------------------------------------------------------------------------------------------
+# file-based outputs: names and log formats of all solvers
+# ----------------------------------------------------------------------------------------------
+def _testset(tmp_path, gray):
+    from PIL import Image
+    ts = tmp_path / 'testsets' / 'Set1'
+    ts.mkdir(parents=True)
+    Image.fromarray(gray).save(ts / '05.png')
+    return str(tmp_path / 'testsets'), tmp_path / 'results'
+
+
+def test_file_names_and_log_formats_follow_each_reference_script(env, golden_inputs, tmp_path):
+    """S1:138/150 ('_PDG L1', PSNR with 2 decimals), S4:144/155 ('_ADMM CNC', 4 decimals),
+    S3:308/320 ('_<model>_PNP_ADMM_L1_D', 2 decimals), S6:320/332 ('PNP_ADMM_CNC_D', 4 decimals, alpha
+    in the average line), S6:536 ('PNP_ADMM_CNC_DnCNN')."""
+    P, S, D = env['P'], env['S'], env['D']
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    noises = golden_inputs['noises']
+    ts, res = _testset(tmp_path, golden_inputs['gray'])
+    kw = dict(testsets=ts, results=str(res))
+    P.ADMM_L1(mask, noises, iter_num=3, lambda1=0.1, reo=0.015, **kw)
+    P.ADMM_CNC(mask, noises, alpha=0.45, iter_num=3, lambda1=0.5, reo=0.05, b=64, **kw)
+    sd = D.seeded_state_dict(D.build('dncnn_15')[0], 1)
+    S.PNP_ADMM_L1_D('dncnn_15', mask, noises, model=sd, iter_num=2, reo=0.15, **kw)
+    S.PNP_ADMM_CNC_D('dncnn_15', mask, noises, model=sd, alpha=0.9, iter_num=2, lambda1=1.0, reo=0.45, b=0.3, **kw)
+    S.PNP_ADMM_CNC_DnCNN('dncnn_25', 'dncnn_15', mask, noises, model=sd, alpha=1.2, iter_num=2, lambda1=4, reo=0.45, b=0.3, **kw)
+    want = {
+        'Set1_dn_ADMM_L1': ('05_PDG L1.png', 2, None),
+        'Set1_dn_ADMM_CNC': ('05_ADMM CNC.png', 4, None),
+        'Set1_dn_dncnn_15': (None, None, None),                    # two solvers share this directory (as in the reference)
+        'Set1_dn_dncnn_25_dncnn_15': ('05PNP_ADMM_CNC_DnCNN.png', 4, 'alpha'),
+    }
+    assert sorted(p.name for p in res.iterdir()) == sorted(want)
+    for d, (png, dec, extra) in want.items():
+        log = (res / d / (d + '.log')).read_text()
+        if png is None:
+            assert sorted(p.name for p in (res / d).glob('*.png')) == ['05PNP_ADMM_CNC_D.png', '05_dncnn_15_PNP_ADMM_L1_D.png']
+            assert re.search(r'05\.png - PSNR: \d+\.\d{2} dB; SSIM: -?\d\.\d{4} ; RE: \d+\.\d{4}\.', log)      # S3:320
+            assert re.search(r'05\.png - PSNR: \d+\.\d{4} dB; SSIM: -?\d\.\d{4} ; RE: \d+\.\d{4}\.', log)      # S6:332
+            assert re.search(r'testset_name: \(Set1\), alpha: \(0\.900\), Average PSNR:', log)                  # S6:345
+            assert re.search(r'testset_name: \(Set1\), Average PSNR:', log)                                     # S3:332
+            continue
+        assert [p.name for p in (res / d).glob('*.png')] == [png]
+        assert re.search(r'05\.png - PSNR: \d+\.\d{%d} dB; SSIM: -?\d\.\d{4} ; RE: \d+\.\d{4}\.' % dec, log)
+        assert not re.search(r'05\.png - PSNR: \d+\.\d{%d} dB' % (6 - dec), log)
+        assert ('alpha: (1.200)' in log) == (extra == 'alpha')
+
+
+def test_mat_inputs_through_the_entry_point(env, golden_inputs, golden_admm, tmp_path):
+    """The reference's whole input path (S4:182-191 + S4:83-94): masks and noises from CS_MRI/*.mat
+    (committed fixture), image from testsets/Set1 -- result equals the golden x of the unmodified script."""
+    from pnp_admm_cnc_mri_amd import imageio as IO
+    P = env['P']
+    mask, noises = IO.load_cs_mri(os.path.join(GOLD, 'cs_mri_fixture'))
+    ts, res = _testset(tmp_path, golden_inputs['gray'])
+    out = P.ADMM_L1(mask[0], noises, testsets=ts, results=str(res), **P.PRESETS['ADMM_L1'])
+    assert rel_l2(out[0], golden_admm['l1_random30_it50']) <= 1e-5
+    out = P.ADMM_CNC(mask[2], noises, testsets=ts, results=str(res), **P.PRESETS['ADMM_CNC'])
+    assert rel_l2(out[0], golden_admm['cnc_cartesian30_it50']) <= 1e-4        # fp32 CNC at 50 iterations
+
+
+# ----------------------------------------------------------------------------------------------
+# edge behaviour
+# ----------------------------------------------------------------------------------------------
+def test_zero_iterations_return_the_initial_x(env, golden_inputs):
+    """iter_num = 0: the reference's loop body never runs and `out` holds x = |ifft2(y)| (S4:103, 138)."""
+    P, S, D = env['P'], env['S'], env['D']
+    mask = golden_inputs['masks']['Q_Radial30'].astype(np.float64)
+    img = golden_inputs['gray'][None]
+    y = O.synthesize(O.requantise(golden_inputs['gray']), mask, golden_inputs['noises'])
+    x0 = np.abs(np.fft.ifft2(y))
+    for out in (P.ADMM_L1(mask, golden_inputs['noises'], images=img, iter_num=0),
+                P.ADMM_CNC(mask, golden_inputs['noises'], images=img, iter_num=0),
+                S.PNP_ADMM_L1_D('dncnn_15', mask, golden_inputs['noises'], images=img, iter_num=0,
+                                model=D.seeded_state_dict(D.build('dncnn_15')[0], 1)),
+                S.PNP_ADMM_CNC_D('dncnn_15', mask, golden_inputs['noises'], images=img, iter_num=0,
+                                 model=D.seeded_state_dict(D.build('dncnn_15')[0], 1))[0]):
+        assert rel_l2(out[0], x0) <= 2e-6
+
+
+@pytest.mark.parametrize('H', [256, 512])
+def test_unsampled_measurements_never_reach_the_result(env, H):
+    """y entries where the mask is 0 are not part of the problem (S4:121-122 reads y[index] only):
+    NaN / Inf there must not poison the fused path (Hermitian tables select, they do not multiply)."""
+    P = env['P']
+    rng = np.random.default_rng(5)
+    mask = (rng.uniform(size=(H, H)) < 0.3).astype(np.uint8)
+    mask[0, 0] = 1
+    B = 3
+    img = np.stack([O.phantom(b, H, H) for b in range(B)])
+    y = np.stack([O.synthesize(img[b], mask, O.kspace_noise(b, H, H)) for b in range(B)]).astype(np.complex64)
+    bad = y.copy()
+    hole = (mask == 0)
+    bad[:, hole] = np.where(rng.uniform(size=int(hole.sum())) < 0.5, np.nan, np.inf).astype(np.float32) * (1 + 1j)
+    res = []
+    for yy in (y, bad):
+        for fast in (1, 0):
+            with P.Engine(H, H, Bmax=B) as eng:
+                eng.set_fast_path(fast)
+                eng.upload(yy, mask)
+                eng.set_state(np.abs(np.fft.ifft2(y * mask)).astype(np.float32), np.zeros((B, H, H), np.float32))
+                eng.admm_cnc(3, 0.45, 0.5, 0.05, 64)
+                res.append(eng.x())
+    assert all(np.isfinite(r).all() for r in res)
+    assert np.array_equal(res[0], res[2]) and np.array_equal(res[1], res[3])
+
+
+def test_device_mask_ids_are_validated(env):
+    """mask_id handed over as a DEVICE array is range-checked like a host array (it indexes the mask bank)."""
+    torch, P = env['torch'], env['P']
+    from pnp_admm_cnc_mri_amd import _lib
+    import ctypes as C
+    B, K = 4, 2
+    y = torch.zeros((B, 256, 256, 2), dtype=torch.float32, device='cuda')
+    bank = torch.ones((K, 256, 256), dtype=torch.uint8, device='cuda')
+    with P.Engine(256, 256, Bmax=B) as eng:
+        L = _lib.lib()
+        good = torch.tensor([0, 1, 1, 0], dtype=torch.int32, device='cuda')
+        assert L.pnp_upload_problem(eng._ctx, C.c_void_p(y.data_ptr()), C.c_void_p(bank.data_ptr()), C.c_void_p(good.data_ptr()), B, K, 1) == 0
+        for badv in ([0, 2, 0, 0], [0, 0, -1, 0]):
+            bad = torch.tensor(badv, dtype=torch.int32, device='cuda')
+            rc = L.pnp_upload_problem(eng._ctx, C.c_void_p(y.data_ptr()), C.c_void_p(bank.data_ptr()), C.c_void_p(bad.data_ptr()), B, K, 1)
+            assert rc == -1 and b'mask_id' in L.pnp_last_error()
+            assert L.pnp_init_state(eng._ctx) == -3                      # no problem is left behind
+        sch = eng.schedule
+        assert set(sch) == {'queues', 'mixed', 'chunk'}
+
+
+# ----------------------------------------------------------------------------------------------
+# PnP coverage
+# ----------------------------------------------------------------------------------------------
+def _ircnn_bank(D, gain=0.5):
+    net, nlm, _ = D.build('ircnn_gray')
+    return {str(k): D.seeded_state_dict(net, 300 + k, gain=gain) for k in range(25)}, nlm
+
+
+@pytest.mark.parametrize('solver', ['cnc', 'l1'])
+def test_ircnn_bank_switches_like_the_reference(env, golden_inputs, solver, tmp_path):
+    """IRCNN's 25-model bank (S6:184-197): the index ceil(sigma_i * 255 / 2) - 1 changes along the
+    sigma schedule and the weights are reloaded on change (S6:289-298, S3:53-62 for the forward).  The
+    reference branch itself cannot run under NumPy 2 (`np.int`), so parity is against the oracle loop
+    driven with the same GPU denoiser and the same switch; 12 iterations walk through 9 bank entries."""
+    torch, D, S = env['torch'], env['D'], env['S']
+    from pnp_admm_cnc_mri_amd import utils_pnp
+    bank, nlm = _ircnn_bank(D)
+    iters = 12
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    y = O.synthesize(O.requantise(golden_inputs['gray']), mask, golden_inputs['noises'])
+    sig = utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1]
+    idx = [int(np.ceil(float(s) * 255. / 2.) - 1) for s in sig]
+    assert idx[0] == 24 and idx[-1] == 7 and len(set(idx)) >= 8
+    net, _, _ = D.build('ircnn_gray')
+    net.load_state_dict(bank['0'])
+    den = D.Denoiser('ircnn_gray', net.eval(), nlm, sigmas=torch.tensor(sig), bank=bank).to(torch.device('cuda'))
+    loaded = []
+
+    def denoise(a, i):
+        den.select_bank(i)
+        loaded.append(den.former_idx)
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return den(t, i)[0, 0].cpu().numpy()
+
+    if solver == 'cnc':
+        opts = dict(alpha=0.5, lambda1=1.3, reo=0.45, b=2)                           # S6:575 preset
+        out, _ = S.PNP_ADMM_CNC_D('ircnn_gray', mask, None, y=y[None], model=bank, results=str(tmp_path), iter_num=iters, **opts)
+        ref = O.pnp_admm_cnc(y, mask, denoise, iters, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
+    else:
+        out = S.PNP_ADMM_L1_D('ircnn_gray', mask, None, y=y[None], model=bank, results=str(tmp_path), iter_num=iters, reo=0.145)   # S3:345
+        ref = O.pnp_admm_l1(y, mask, denoise, iters, 0.145)
+    assert sorted(set(loaded)) == sorted(set(idx))
+    assert rel_l2(out[0], ref) <= 1e-5, rel_l2(out[0], ref)
+    # the switch matters: a run pinned to bank entry 0 gives a different image
+    pinned = (S.PNP_ADMM_CNC_D('ircnn_gray', mask, None, y=y[None], model=bank['0'], results=str(tmp_path), iter_num=iters, **opts)[0]
+              if solver == 'cnc' else
+              S.PNP_ADMM_L1_D('ircnn_gray', mask, None, y=y[None], model=bank['0'], results=str(tmp_path), iter_num=iters, reo=0.145))
+    assert rel_l2(pinned[0], ref) > 1e-3
+
+
+def test_x8_all_eight_modes_against_the_reference(env, golden_inputs, tmp_path):
+    """PNP_ADMM_L1_D('drunet_gray') for 9 iterations: the x8 cycle i % 8 visits every view, including
+    modes 3 and 5 whose inverse is 8 - i % 8 (S3:40-50).  (1) golden x of the unmodified S3 script
+    (CPU conv vs MIOpen conv: 2e-4 as for the 3-iteration fixtures); (2) oracle loop with the same GPU
+    denoiser <= 1e-5; (3) swapping the inverse of modes 3/5 is caught."""
+    torch, D, S = env['torch'], env['D'], env['S']
+    from pnp_admm_cnc_mri_amd import utils_pnp
+    name = 'drunet_gray'
+    opts = dict(env['known']['l1_d_drunet_gray_it9_opts'])
+    iters = int(opts.pop('iter_num'))
+    assert iters == 9
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    net, nlm, _ = D.build(name)
+    sd = D.seeded_state_dict(net, env['known']['seeds'][name])
+    out = S.PNP_ADMM_L1_D(name, mask, golden_inputs['noises'], images=golden_inputs['gray'][None], model=sd,
+                          results=str(tmp_path), iter_num=iters, **opts)
+    ref = env['gold']['l1_d_drunet_gray_it9']
+    assert rel_l2(out[0], ref) <= 2e-4, rel_l2(out[0], ref)
+
+    net.load_state_dict(sd)
+    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, x8=True).to(torch.device('cuda'))
+
+    def denoise(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return den(t, i)[0, 0].cpu().numpy()
+
+    y = O.synthesize(O.requantise(golden_inputs['gray']), mask, golden_inputs['noises'])
+    refo = O.pnp_admm_l1(y, mask, denoise, iters, opts['reo'])
+    assert rel_l2(out[0], refo) <= 1e-5, rel_l2(out[0], refo)
+
+    class WrongInverse(D.Denoiser):
+        def _one(self, x, i):
+            x = D.augment_img_tensor4(x, i % 8)
+            s = self.sigmas[i].float().reshape(1, 1, 1, 1).expand(x.shape[0], 1, x.shape[2], x.shape[3])
+            x = D.test_mode(self.model, torch.cat((x, s), dim=1), mode=2, refield=32, min_size=256, modulo=16)
+            return D.augment_img_tensor4(x, i % 8)                    # modes 3 and 5 NOT inverted by their partner
+    bad = WrongInverse(name, net, nlm, sigmas=sig, x8=True).to(torch.device('cuda'))
+
+    def denoise_bad(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return bad(t, i)[0, 0].cpu().numpy()
+    assert rel_l2(O.pnp_admm_l1(y, mask, denoise_bad, iters, opts['reo']), ref) > 1e-2
+
+
+def test_config3_full_batch_properties(env):
+    """Config 3 at full size: PNP_ADMM_CNC_D with FFDNet on 512 slices of 256x256, Q_Radial30, S6:573
+    preset, 2 iterations.  Size-independent properties: (a) a 64-slice sub-batch run alone is
+    bit-equal to the same slices inside the full batch; (b) slices are independent -- permuting the
+    batch permutes the result; (c) oracle-loop spot check on the first and the last slice."""
+    torch, D, S = env['torch'], env['D'], env['S']
+    from pnp_admm_cnc_mri_amd import synthetic as SY
+    B = 512
+    mask = SY.reference_masks()['Q_Radial30'].astype(np.uint8)
+    with env['P'].Engine(256, 256, Bmax=B) as eng:                               # measurements on the device
+        img, noise = SY.batch(0, B)
+        eng.synthesize(img, noise, mask)
+        ys = eng.download_y()
+    name = 'ffdnet_gray'
+    net, nlm, _ = D.build(name)
+    sd = D.seeded_state_dict(net, 1001)
+    opts = dict(alpha=0.9, iter_num=2, lambda1=1.35, reo=0.45, b=0.3)            # S6:573, 2 iterations
+    full, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys, model=sd, **opts)
+    full = np.stack(full[:B])
+    assert full.shape == (B, 256, 256) and np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
+    sub, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[128:192], model=sd, **opts)
+    assert np.array_equal(np.stack(sub[:64]), full[128:192])
+    perm = np.random.default_rng(0).permutation(B)
+    pm, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[perm], model=sd, **opts)
+    pm = np.stack(pm[:B])
+    assert np.abs(pm - full[perm]).max() <= 2e-6                                # conv batches regroup: rounding only
+    net.load_state_dict(sd)
+    den = D.Denoiser(name, net.eval(), nlm).to(torch.device('cuda'))
+
+    def denoise(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return den(t, i)[0, 0].cpu().numpy()
+    for b in (0, B - 1):
+        ref = O.pnp_admm_cnc(ys[b].astype(np.complex128), mask, denoise, 2, 0.9, 1.35, 0.45, 0.3)
+        assert rel_l2(full[b], ref) <= 1e-5, (b, rel_l2(full[b], ref))

@@ -132,3 +132,68 @@ def test_solve_sharded_entry_point_shape():
 def test_run_sharded_without_process_group():
     x = sharding.run_sharded(_solve, 3)
     assert x.shape == (3, 64, 64)
+
+
+def _noisy_solver(mask, noises, images=None, y=None, mask_id=None, **opts):
+    """entry-point shape with `images` + per-slice k-space noise [b,H,W]: synthesises y like S4:102,
+    and (like Engine.synthesize) refuses a noise batch that does not match the images."""
+    noises = np.asarray(noises)
+    if noises.ndim == 3 and noises.shape[0] != len(images):
+        raise ValueError('noise batch does not match images')
+    out = [np.zeros(mask.shape[-2:], np.uint8)] * max(22, len(images))
+    for n in range(len(images)):
+        nz = noises[n] if noises.ndim == 3 else noises
+        out[n] = O.admm_l1(O.synthesize(images[n], mask, nz), mask, 2)
+    return out
+
+
+def _noisy_problem(B=5):
+    rng = np.random.default_rng(3)
+    mask = (rng.uniform(size=(64, 64)) < 0.4).astype(np.float64)
+    mask[0, 0] = 1
+    imgs = rng.uniform(0, 1, (B, 64, 64)).astype(np.float32)
+    noises = (rng.standard_normal((B, 64, 64)) + 1j * rng.standard_normal((B, 64, 64))) * 0.5
+    return mask, noises, imgs
+
+
+def _worker_noisy(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mask, noises, imgs = _noisy_problem()
+        # (1) per-slice noise, uneven shards (2 + 2 + 1), gathered on global rank 0
+        x = sharding.solve_sharded(_noisy_solver, mask, noises, images=imgs)
+        assert (x is not None) == (rank == 0)
+        # (2) a sub-group {1, 2} gathering on GLOBAL rank 2 (group-local rank 1)
+        grp = dist.new_group([1, 2])
+        x2 = None
+        if rank in (1, 2):
+            x2 = sharding.solve_sharded(_noisy_solver, mask, noises, images=imgs, dst=2, group=grp)
+            assert (x2 is not None) == (rank == 2)
+        if rank == 0:
+            q.put(('all', x))
+        if rank == 2:
+            q.put(('sub', x2))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_solve_sharded_per_slice_noise_and_subgroup_dst():
+    """per-slice noise [B,H,W] is sharded with the slices (uneven shards over 3 ranks), and `dst` is a
+    global rank also when the job runs in a sub-group."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_noisy, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    mask, noises, imgs = _noisy_problem()
+    ref = sharding.solve_sharded(_noisy_solver, mask, noises, images=imgs)
+    assert got['all'].shape == (5, 64, 64) and np.array_equal(got['all'], ref)
+    assert np.array_equal(got['sub'], ref)

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from oracle import admm_oracle as O
 from pnp_admm_cnc_mri_amd import synthetic as S
@@ -30,16 +31,11 @@ def test_reference_masks_fixture(golden_inputs):
     assert all(m[k][0, 0] == 1 for k in m)
 
 
-def test_host_metrics_and_imageio_match_the_oracle(golden_inputs, golden_admm, tmp_path):
-    """pnp_admm_cnc_mri_amd.metrics / imageio (host utilities at the edges of the solvers) against the
-    oracle's restatement of utils/utils_image.py."""
-    from pnp_admm_cnc_mri_amd import metrics as M, imageio as IO
+def test_imageio_matches_the_oracle(golden_inputs, golden_admm, tmp_path):
+    """pnp_admm_cnc_mri_amd.imageio (host utilities at the edges of the solvers) against the oracle's
+    restatement of utils/utils_image.py."""
+    from pnp_admm_cnc_mri_amd import imageio as IO
     gt = golden_inputs['gray']
-    x = golden_admm['cnc_random30_it50']
-    assert abs(M.calculate_psnr(x * 255, gt) - O.calculate_psnr(x * 255, gt)) <= 1e-12
-    assert abs(M.calculate_re(x * 255, gt) - O.calculate_re(x * 255, gt)) <= 1e-15
-    assert abs(M.calculate_ssim(x * 255, gt) - O.calculate_ssim(x * 255, gt)) <= 1e-12
-    assert abs(M.psnr(x * 255, gt.astype(np.float64)) - O.psnr255(x * 255, gt.astype(np.float64))) <= 1e-12
     assert np.array_equal(IO.requantise(gt), O.requantise(gt))
     # gray decode: an RGB(A) PNG goes through OpenCV's fixed-point formula, an L PNG is taken as is
     from PIL import Image
@@ -52,3 +48,41 @@ def test_host_metrics_and_imageio_match_the_oracle(golden_inputs, golden_admm, t
     assert np.array_equal(IO.imread_gray(str(tmp_path / 'g.png')), rgb[..., 0])
     assert IO.modcrop(np.zeros((21, 19)), 8).shape == (16, 16)
     assert [os.path.basename(p) for p in IO.get_image_paths(str(tmp_path))] == ['c.png', 'g.png']
+
+
+def test_cs_mri_mat_path(golden_inputs, known_answers, tmp_path):
+    """S4:182-191 through imageio.load_cs_mri on the committed .mat fixture (tests/golden/cs_mri_fixture,
+    written by tests/golden/make_cs_mri_fixture.py in the reference's Q1 / Q11 / OMEGA layout):
+    float64 Q1 masks, complex128 noises x 3.0, and the three views of a pattern must agree."""
+    import scipy.io as sio
+    from pnp_admm_cnc_mri_amd import imageio as IO
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cs_mri_fixture')
+    mask, noises = IO.load_cs_mri(root)
+    assert mask.dtype == np.float64 and mask.shape == (3, 256, 256)
+    assert noises.dtype == np.complex128 and noises.shape == (256, 256)
+    for k, name in enumerate(IO.MASK_NAMES):
+        assert np.array_equal(mask[k], golden_inputs['masks'][name])
+        rec = known_answers['cs_mri'][name]                  # what oracle/make_golden.py found in the reference's files
+        d = sio.loadmat(os.path.join(root, name + '.mat'))
+        assert sorted(v for v in d if not v.startswith('__')) == rec['variables']
+        assert int(mask[k].sum()) == rec['sampled'] and rec['Q11_is_fftshift_Q1']
+        assert d['Q1'].dtype == np.uint8 and np.array_equal(d['Q11'], np.fft.fftshift(d['Q1']))
+        if 'OMEGA' in d:
+            assert rec['OMEGA_is_find_Q1'] and d['OMEGA'].shape == (rec['sampled'], 1)
+            assert np.array_equal(d['OMEGA'].ravel(), np.flatnonzero(d['Q1'].T.ravel()) + 1)
+    assert np.array_equal(noises, golden_inputs['noises'])
+    # a file that holds only the centred view is converted; inconsistent views are refused
+    q1 = golden_inputs['masks']['Q_Random30']
+    sio.savemat(tmp_path / 'only_q11.mat', {'Q11': np.fft.fftshift(q1)})
+    assert np.array_equal(IO.load_mask_mat(str(tmp_path / 'only_q11.mat')), q1)
+    sio.savemat(tmp_path / 'bad_q11.mat', {'Q1': q1, 'Q11': q1})
+    with pytest.raises(ValueError, match='Q11'):
+        IO.load_mask_mat(str(tmp_path / 'bad_q11.mat'))
+    om = (np.flatnonzero(q1.ravel()) + 1).astype(np.int32)[:, None]          # row-major: not MATLAB's find()
+    sio.savemat(tmp_path / 'bad_omega.mat', {'Q1': q1, 'OMEGA': om})
+    with pytest.raises(ValueError, match='OMEGA'):
+        IO.load_mask_mat(str(tmp_path / 'bad_omega.mat'))
+    assert np.array_equal(IO.load_mask_mat(str(tmp_path / 'bad_omega.mat'), check=False), q1)
+    sio.savemat(tmp_path / 'none.mat', {'foo': q1})
+    with pytest.raises(ValueError, match='neither'):
+        IO.load_mask_mat(str(tmp_path / 'none.mat'))
