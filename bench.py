@@ -183,7 +183,15 @@ def main():
     else:
         masks = np.stack([S.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
         mask_id = (np.arange(B) % 3).astype(np.int32)
-    img, noise = S.batch(rank * B, B, H, W)                           # this rank's shard of the job
+    cache = os.environ.get('PNP_BENCH_CACHE')                         # repeated runs: reuse the generated inputs
+    cpath = cache and '%s.r%d.b%d.n%d.npz' % (cache, rank, B, H)
+    if cpath and os.path.exists(cpath):
+        d = np.load(cpath)
+        img, noise = d['img'], d['noise']
+    else:
+        img, noise = S.batch(rank * B, B, H, W)                       # this rank's shard of the job
+        if cpath:
+            np.savez(cpath, img=img, noise=noise)
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)
     if args.generic:

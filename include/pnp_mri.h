@@ -92,7 +92,9 @@ int pnp_set_state(pnp_ctx* ctx, const float* z, const float* w, int on_device);
 int pnp_get_state(pnp_ctx* ctx, float* z, float* w, int on_device);
 
 /* ---- whole loops on the ctx-owned state (no host sync inside) ----------------------------- */
-/* ADMM_L1 main loop, S1:111-126:  x = dc(z,w); z = soft(x+w, reo*lambda1); w += x - z. */
+/* iters = 0: the loop body never runs; x is set to the current z (the reference's x = |ifft2(y)| = z0
+ * straight after pnp_init_state, S4:103-107, 138).
+ * ADMM_L1 main loop, S1:111-126:  x = dc(z,w); z = soft(x+w, reo*lambda1); w += x - z. */
 int pnp_admm_l1_run(pnp_ctx* ctx, int iters, double lambda1, double reo);
 /* ADMM_CNC main loop, S4:115-132: x = dc(z,w); s = soft(z,1/b);
  * t = (1-alpha) z + alpha (x+w) + alpha*reo*lambda1*b (z-s); z = soft(t, alpha*reo*lambda1);

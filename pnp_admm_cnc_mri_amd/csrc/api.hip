@@ -77,6 +77,8 @@ struct pnp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Fused256* fused = nullptr;        // 256 x 256
     Fused512* fused5 = nullptr;       // 512 x 512
+    Fused256S<float>* fs32 = nullptr;   // 256 x 256 "split chain" engine in float (PNP_FUSED_COLS=2) ...
+    Fused256S<double>* fs64 = nullptr;  // ... and in double: the fast path of an fp64 context
     FusedSchedule sched;              // defaults overridable by PNP_FUSED_* (read at creation) / pnp_set_schedule
     bool fused_ready = false;         // tables prepared for the current problem
     // fp64 validation context (pnp_ctx_create_f64): same loop, generic kernels, double buffers
@@ -104,7 +106,7 @@ static ProxParams make_prox_cnc(double alpha, double lambda1, double reo, double
 }
 static float dc_coeff(double reo) { return (float)(1.0 / (1.0 + 1.0 / 2.0 / reo)); }
 
-static bool use_fused(pnp_ctx* c) { return c->fast && (c->fused || c->fused5) && c->fused_ready; }
+static bool use_fused(pnp_ctx* c) { return c->fast && (c->fused || c->fused5 || c->fs32 || c->fs64) && c->fused_ready; }
 
 extern "C" {
 
@@ -160,11 +162,13 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
         pnp_ctx_destroy(c);
         return fail(e == hipErrorOutOfMemory ? PNP_E_NOMEM : PNP_E_HIP, "pnp_ctx_create: %s", hipGetErrorString(e));
     }
-    if (!f64 && H == W) {
+    if (H == W && (!f64 || H == 256)) {
         hipError_t fe = hipSuccess;
-        if (H == 256) c->fused = fused256_create(Bmax, &fe);
-        else          c->fused5 = fused512_create(Bmax, &fe);
-        if (!c->fused && !c->fused5) {
+        if (f64)                                         c->fs64 = fused256s_create<double>(Bmax, &fe);
+        else if (H == 256 && env_int("PNP_FUSED_COLS", 1) == 2) c->fs32 = fused256s_create<float>(Bmax, &fe);
+        else if (H == 256)                               c->fused = fused256_create(Bmax, &fe);
+        else                                             c->fused5 = fused512_create(Bmax, &fe);
+        if (!c->fused && !c->fused5 && !c->fs32 && !c->fs64) {
             pnp_ctx_destroy(c);
             return fail(PNP_E_HIP, "pnp_ctx_create: fused path: %s", hipGetErrorString(fe));
         }
@@ -181,6 +185,8 @@ int pnp_ctx_destroy(pnp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->fused) fused256_destroy(c->fused);
     if (c->fused5) fused512_destroy(c->fused5);
+    if (c->fs32) fused256s_destroy(c->fs32);
+    if (c->fs64) fused256s_destroy(c->fs64);
     void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage, c->ssim_part,
                     c->yd, c->workd, c->zd, c->wd, c->xd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -261,6 +267,12 @@ static int prepare_fused(pnp_ctx* c) {
         c->fused_ready = true;
     } else if (c->fused5) {
         HIPCHK(fused512_prepare(c->fused5, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
+        c->fused_ready = true;
+    } else if (c->fs32) {
+        HIPCHK(fused256s_prepare<float>(c->fs32, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
+        c->fused_ready = true;
+    } else if (c->fs64) {
+        HIPCHK(fused256s_prepare<double>(c->fs64, c->stream, c->yd, c->mask_bank, c->mask_id, c->B));
         c->fused_ready = true;
     }
     return PNP_OK;
@@ -378,6 +390,12 @@ static int generic_iteration(pnp_ctx* c, const float* z_in, const float* w_in, R
 
 static int run_loop_f64(pnp_ctx* c, int iters, bool cnc, const ProxParamsT<double>& pp, double reo) {
     const double cdc = 1.0 / (1.0 + 1.0 / 2.0 / reo);
+    if (iters == 0) HIPCHK(hipMemcpyAsync(c->xd, c->zd, (size_t)c->B * c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (iters > 0 && use_fused(c)) {
+        HIPCHK(fused256s_run<double>(c->fs64, c->stream, c->zd, c->wd, c->xd, c->B, iters, cnc, cdc, pp, c->sched));
+        c->have_x = true;
+        return PNP_OK;
+    }
     for (int i = 0; i < iters; ++i) {
         RowArgsT<double> ra{};
         ra.rin0 = c->zd; ra.rin1 = c->wd; ra.cout = c->workd; ra.scale = 1.0; ra.nrows = c->B * c->H;
@@ -398,11 +416,17 @@ static int run_loop_f64(pnp_ctx* c, int iters, bool cnc, const ProxParamsT<doubl
 static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, double reo) {
     if (iters < 0) return fail(PNP_E_ARG, "iters must be >= 0");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "reo must be > 0");
-    if (iters == 0) return PNP_OK;
+    if (iters == 0) {
+        // the reference's loop body never runs and its x stays the initial x = |ifft2(y)| = z0 (S4:103, 107, 138)
+        HIPCHK(hipMemcpyAsync(c->x, c->z, (size_t)c->B * c->N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        c->have_x = true;
+        return PNP_OK;
+    }
     const float cdc = dc_coeff(reo);
     if (use_fused(c)) {
-        if (c->fused) HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
-        else          HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        if (c->fused)       HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        else if (c->fs32)   HIPCHK(fused256s_run<float>(c->fs32, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        else                HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
     } else {
         for (int i = 0; i < iters; ++i) {
             int rc = generic_iteration(c, c->z, c->w, cnc ? EPI_CNC : EPI_L1, pp, cdc,
@@ -451,8 +475,9 @@ int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo
     if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
     if (use_fused(c)) {
-        if (c->fused) HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
-        else          HIPCHK(fused512_dc(c->fused5, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        if (c->fused)     HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        else if (c->fs32) HIPCHK(fused256s_dc<float>(c->fs32, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        else              HIPCHK(fused512_dc(c->fused5, c->stream, z, w, x, c->B, dc_coeff(reo)));
         return PNP_OK;
     }
     return generic_iteration(c, z, w, EPI_ABS_REAL, ProxParams{}, dc_coeff(reo), x, nullptr, nullptr);
@@ -614,7 +639,7 @@ int pnp_upload_problem_f64(pnp_ctx* c, const double* y, const uint8_t* mask_bank
     if (rc) { c->B = 0; return rc; }
     rc = copy_in(c, c->yd, y, (size_t)B * c->N * sizeof(double2), on_device);
     if (rc) { c->B = 0; return rc; }
-    return PNP_OK;
+    return prepare_fused(c);
 }
 
 int pnp_set_state_f64(pnp_ctx* c, const double* z, const double* w, int on_device) {
@@ -658,6 +683,7 @@ int pnp_timer_stop(pnp_ctx* c, float* ms) {
 int pnp_kernels_per_iteration(pnp_ctx* c) {
     if (!c) return 0;
     if (!use_fused(c)) return 3;                      // generic: rows, columns, rows
+    if (c->fs32 || c->fs64) return (c->sched.queues >= 2 && c->B >= 64 && c->sched.chunk <= 0) ? 4 : 2;
     const int q = (c->fused5 || c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
     return 2 * q;                                     // two launches per queue and batched iteration
 }

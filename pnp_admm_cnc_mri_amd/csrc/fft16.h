@@ -20,51 +20,60 @@
 
 namespace pnp {
 
-struct c32 {
-    float x, y;
+// complex value in the real type R: float for the production path, double for the fp64 engine
+template <typename R>
+struct cxT {
+    R x, y;
 };
+using c32 = cxT<float>;
+using c64 = cxT<double>;
 
-PNP_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
-PNP_HD c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
-PNP_HD c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+template <typename R> PNP_HD cxT<R> mk(R x, R y) { cxT<R> r; r.x = x; r.y = y; return r; }
+template <typename R> PNP_HD cxT<R> operator+(cxT<R> a, cxT<R> b) { return mk<R>(a.x + b.x, a.y + b.y); }
+template <typename R> PNP_HD cxT<R> operator-(cxT<R> a, cxT<R> b) { return mk<R>(a.x - b.x, a.y - b.y); }
 // The library is compiled with -ffp-contract=off and every fused multiply-add is written out, so
 // the rounding sequence is fixed by this source and identical in every kernel instantiation
 // (bit-identical results whether a run is split into several calls or not) and on the host.
 PNP_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-PNP_HD c32 mul(c32 a, c32 b) { return mk(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
-PNP_HD c32 mulc(c32 a, c32 b) { return mk(fma_(a.x, b.x, a.y * b.y), fma_(a.y, b.x, -(a.x * b.y))); }   // a*conj(b)
-template <bool INV> PNP_HD c32 tmul(c32 a, c32 w) { return INV ? mulc(a, w) : mul(a, w); }
+PNP_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename R> PNP_HD cxT<R> mul(cxT<R> a, cxT<R> b) { return mk<R>(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
+template <typename R> PNP_HD cxT<R> mulc(cxT<R> a, cxT<R> b) { return mk<R>(fma_(a.x, b.x, a.y * b.y), fma_(a.y, b.x, -(a.x * b.y))); }   // a*conj(b)
+template <bool INV, typename R> PNP_HD cxT<R> tmul(cxT<R> a, cxT<R> w) { return INV ? mulc(a, w) : mul(a, w); }
 // multiply by -i (forward) / +i (inverse)
-template <bool INV> PNP_HD c32 rot(c32 a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+template <bool INV, typename R> PNP_HD cxT<R> rot(cxT<R> a) { return INV ? mk<R>(-a.y, a.x) : mk<R>(a.y, -a.x); }
 
-template <bool INV>
-PNP_HD void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
-    const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
+template <bool INV, typename R>
+PNP_HD void dft4(cxT<R>& a0, cxT<R>& a1, cxT<R>& a2, cxT<R>& a3) {
+    const cxT<R> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
     a0 = t0 + t2;
     a1 = t1 + t3;
     a2 = t0 - t2;
     a3 = t1 - t3;
 }
 
+// the float constants below are the correctly rounded values of the double literals
+static_assert((float)0.92387953251128674 == 0.92387953251128674f && (float)0.38268343236508977 == 0.38268343236508977f &&
+              (float)0.70710678118654752 == 0.70710678118654752f, "constant rounding");
+
 // a[k] <- sum_n a[n] W16^(nk)   (W16 = exp(-2 pi i/16); conjugated when INV), natural order.
-template <bool INV>
-PNP_HD void dft16(c32 (&a)[16]) {
-    constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
-    constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
-    constexpr float H = 0.70710678118654752f;    // sqrt(1/2)
+template <bool INV, typename R>
+PNP_HD void dft16(cxT<R> (&a)[16]) {
+    const R C1 = (R)0.92387953251128674;   // cos(pi/8)
+    const R S1 = (R)0.38268343236508977;   // sin(pi/8)
+    const R H = (R)0.70710678118654752;    // sqrt(1/2)
     // step 1: for n0: DFT4 over n1 of a[n0 + 4 n1]  -> b[n0][k1] stored at a[n0 + 4 k1]
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4<INV>(a[n0], a[n0 + 4], a[n0 + 8], a[n0 + 12]);
     // step 2: b[n0][k1] *= W16^(n0*k1)   (forward values; tmul conjugates for INV)
-    a[1 + 4] = tmul<INV>(a[1 + 4], mk(C1, -S1));     // W^1
-    a[1 + 8] = tmul<INV>(a[1 + 8], mk(H, -H));       // W^2
-    a[1 + 12] = tmul<INV>(a[1 + 12], mk(S1, -C1));   // W^3
-    a[2 + 4] = tmul<INV>(a[2 + 4], mk(H, -H));       // W^2
-    a[2 + 8] = rot<INV>(a[2 + 8]);                   // W^4 = -i
-    a[2 + 12] = tmul<INV>(a[2 + 12], mk(-H, -H));    // W^6
-    a[3 + 4] = tmul<INV>(a[3 + 4], mk(S1, -C1));     // W^3
-    a[3 + 8] = tmul<INV>(a[3 + 8], mk(-H, -H));      // W^6
-    a[3 + 12] = tmul<INV>(a[3 + 12], mk(-C1, S1));   // W^9
+    a[1 + 4] = tmul<INV>(a[1 + 4], mk<R>(C1, -S1));     // W^1
+    a[1 + 8] = tmul<INV>(a[1 + 8], mk<R>(H, -H));       // W^2
+    a[1 + 12] = tmul<INV>(a[1 + 12], mk<R>(S1, -C1));   // W^3
+    a[2 + 4] = tmul<INV>(a[2 + 4], mk<R>(H, -H));       // W^2
+    a[2 + 8] = rot<INV>(a[2 + 8]);                      // W^4 = -i
+    a[2 + 12] = tmul<INV>(a[2 + 12], mk<R>(-H, -H));    // W^6
+    a[3 + 4] = tmul<INV>(a[3 + 4], mk<R>(S1, -C1));     // W^3
+    a[3 + 8] = tmul<INV>(a[3 + 8], mk<R>(-H, -H));      // W^6
+    a[3 + 12] = tmul<INV>(a[3 + 12], mk<R>(-C1, S1));   // W^9
     // step 3: for k1: DFT4 over n0 of b[n0][k1] -> X[k1 + 4 k0]; b[n0][k1] sits at a[n0 + 4 k1]
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
@@ -73,22 +82,22 @@ PNP_HD void dft16(c32 (&a)[16]) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = i + 1; j < 4; ++j) {
-            const c32 tmp = a[4 * i + j];
+            const cxT<R> tmp = a[4 * i + j];
             a[4 * i + j] = a[4 * j + i];
             a[4 * j + i] = tmp;
         }
 }
 
 // steps (1)+(2) for one lane; tw[k] = W256^(t*k) (forward values)
-template <bool INV>
-PNP_HD void fft256_head(c32 (&a)[16], const c32 (&tw)[16]) {
+template <bool INV, typename R>
+PNP_HD void fft256_head(cxT<R> (&a)[16], const cxT<R> (&tw)[16]) {
     dft16<INV>(a);
 #pragma unroll
     for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[k]);
 }
 // step (4)
-template <bool INV>
-PNP_HD void fft256_tail(c32 (&a)[16]) { dft16<INV>(a); }
+template <bool INV, typename R>
+PNP_HD void fft256_tail(cxT<R> (&a)[16]) { dft16<INV>(a); }
 
 // ----------------------------------------------------------------------------------------------
 // 512 = 16 points x 32 lanes.  Two lane layouts:
@@ -138,24 +147,26 @@ PNP_HD void fft512_b2(c32 (&a)[16], const c32* tw, int t) {            // after 
 // ----------------------------------------------------------------------------------------------
 // z / w updates shared by all kernels (S1:123-126, S4:127-132)
 // ----------------------------------------------------------------------------------------------
-struct ProxCoef {
-    float thr, c1, c2, c3, ib;
+template <typename R>
+struct ProxCoefT {
+    R thr, c1, c2, c3, ib;
 };
+using ProxCoef = ProxCoefT<float>;
 
-PNP_HD float soft_thr(float a, float c) {
-    const float m = (a < 0 ? -a : a) - c;
-    const float r = m > 0 ? m : 0.0f;
+template <typename R> PNP_HD R soft_thr(R a, R c) {
+    const R m = (a < 0 ? -a : a) - c;
+    const R r = m > 0 ? m : (R)0;
     return a < 0 ? -r : r;
 }
-PNP_HD void prox_l1_pt(float x, float& z, float& w, const ProxCoef& p) {
-    const float u = x + w;
+template <typename R> PNP_HD void prox_l1_pt(R x, R& z, R& w, const ProxCoefT<R>& p) {
+    const R u = x + w;
     z = soft_thr(u, p.thr);
     w = u - z;
 }
-PNP_HD void prox_cnc_pt(float x, float& z, float& w, const ProxCoef& p) {
-    const float u = x + w;
-    const float cz = z < -p.ib ? -p.ib : (z > p.ib ? p.ib : z);   // z - soft(z, 1/b)
-    const float t = fma_(p.c1, z, fma_(p.c2, u, p.c3 * cz));
+template <typename R> PNP_HD void prox_cnc_pt(R x, R& z, R& w, const ProxCoefT<R>& p) {
+    const R u = x + w;
+    const R cz = z < -p.ib ? -p.ib : (z > p.ib ? p.ib : z);   // z - soft(z, 1/b)
+    const R t = fma_(p.c1, z, fma_(p.c2, u, p.c3 * cz));
     z = soft_thr(t, p.thr);
     w = u - z;
 }
@@ -179,4 +190,24 @@ PNP_HD void blend_pair(c32& P, c32& Q, c32 yha, c32 yhb, int ma, int mb, float c
     Q = mk(xax + xby, xbx - xay);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// The same blend written per slice ("split chains", kernels_fused256.hip k_fcols2).  With
+//   p[r] = T[r][k2],  q[r] = T[r][-k2]   (row-transformed field of the pair, one column and its mirror)
+// the row transforms of the two REAL slices are  Ta[r][k2] = (p + conj q)/2,  Tb[r][k2] = (p - conj q)/(2i)
+// (a real signal's transform is Hermitian), so the unpack can be done BEFORE the column transform
+// and each slice runs its own chain  column FFT -> blend -> inverse column FFT:
+//   X = V (1 - c Mh) + c Yh,   code = 2 Mh in {0,1,2},  ch = c/2.
+// The blended field is again Hermitian in k2:  p' = xa' + i xb',  q' = conj(xa') + i conj(xb').
+// ----------------------------------------------------------------------------------------------
+template <typename R> PNP_HD cxT<R> unpack_a(cxT<R> p, cxT<R> q) { return mk<R>((R)0.5 * (p.x + q.x), (R)0.5 * (p.y - q.y)); }
+template <typename R> PNP_HD cxT<R> unpack_b(cxT<R> p, cxT<R> q) { return mk<R>((R)0.5 * (p.y + q.y), (R)0.5 * (q.x - p.x)); }
+template <typename R> PNP_HD cxT<R> blend_one(cxT<R> V, cxT<R> yh, int code, R c, R ch) {
+    const R A = fma_(-ch, (R)code, (R)1);
+    return mk<R>(fma_(A, V.x, c * yh.x), fma_(A, V.y, c * yh.y));
+}
+template <typename R> PNP_HD cxT<R> repack_p(cxT<R> xa, cxT<R> xb) { return mk<R>(xa.x - xb.y, xa.y + xb.x); }
+template <typename R> PNP_HD cxT<R> repack_q(cxT<R> xa, cxT<R> xb) { return mk<R>(xa.x + xb.y, xb.x - xa.y); }
+
 }  // namespace pnp
+

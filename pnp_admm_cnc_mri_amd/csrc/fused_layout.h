@@ -50,6 +50,39 @@ PNP_HD void hermitian_entry(const c32* y, const uint8_t* mask, int k1, int k2, c
 }
 
 // ----------------------------------------------------------------------------------------------
+// "Split chain" tables (k_fcols2 in kernels_fused256.hip; float and double): each thread runs the
+// column chain of ONE slice, thread pairs (slice a, slice b) sit in neighbouring lanes:
+//   lane = s + 2 kl + 16 tq   (s = slice of the pair, kl = 0..7 column pair in the tile, t = 4 wave + tq)
+//   tile m = 0..15: k2 = 8 m + kl (k2 = 0 unused),  tile 16: the self-mirrored columns, kl 0 -> k2 = 0, kl 1 -> k2 = 128
+//   Yh2 : [pair][tile 17][wave 4][j 16][lane 64] complex   Yh_s at k1 = t + 16 j
+//   Mh2 : [pair][tile 17][wave 4][lane 64] u32, 2 bits per j = 2 Mh_s
+// again thread order: every wave-level operand load is one contiguous 512-byte (float) access.
+// ----------------------------------------------------------------------------------------------
+constexpr int F2_TILES = 17;
+constexpr size_t YH2_PAIR = (size_t)F2_TILES * 4 * 16 * 64;      // complex values per slice pair
+constexpr size_t MH2_PAIR = (size_t)F2_TILES * 4 * 64;           // u32 per slice pair
+PNP_HD int f2_tile(int k2) { return (k2 == 0 || k2 == 128) ? 16 : (k2 >> 3); }
+PNP_HD int f2_kl(int k2) { return k2 == 0 ? 0 : (k2 == 128 ? 1 : (k2 & 7)); }
+PNP_HD size_t yh2_index(int pair, int k2, int j, int t, int s) {
+    const int lane = s + 2 * f2_kl(k2) + 16 * (t & 3);
+    return (size_t)pair * YH2_PAIR + ((((size_t)(f2_tile(k2) * 4 + (t >> 2)) * 16 + j) * 64) + lane);
+}
+PNP_HD size_t mh2_index(int pair, int k2, int t, int s) {
+    const int lane = s + 2 * f2_kl(k2) + 16 * (t & 3);
+    return (size_t)pair * MH2_PAIR + ((size_t)(f2_tile(k2) * 4 + (t >> 2)) * 64 + lane);
+}
+// Hermitian-symmetrised measurement and mask code of one slice at (k1, k2), any precision
+template <typename R>
+PNP_HD void hermitian_entry_t(const cxT<R>* y, const uint8_t* mask, int k1, int k2, cxT<R>& yh, int& code) {
+    const int i1 = k1 * F_N + k2;
+    const int i2 = ((F_N - k1) & 255) * F_N + ((F_N - k2) & 255);
+    const int m1 = mask[i1] != 0, m2 = mask[i2] != 0;
+    const cxT<R> y1 = y[i1], y2 = y[i2];
+    yh = mk<R>((R)0.5 * ((m1 ? y1.x : (R)0) + (m2 ? y2.x : (R)0)), (R)0.5 * ((m1 ? y1.y : (R)0) - (m2 ? y2.y : (R)0)));
+    code = m1 + m2;
+}
+
+// ----------------------------------------------------------------------------------------------
 // 512 x 512: same scheme, 32 lanes per transform (fft16.h, "512 = 16 points x 32 lanes").
 //   T  : [pair][r][phi512(k2)] c32, 2 MiB per pair; phi512: [0]=col 0, [1]=col 256, [2q]=col q, [2q+1]=col 512-q
 //   Yh : [pair][tile m:33][wave:4][reg q:16][lane:64] float4,  Mh : [pair][tile][wave][lane] u64

@@ -74,7 +74,7 @@ hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double*
 // How the fused loops are scheduled (scheduling only: results are bit-identical for every setting).
 struct FusedSchedule {
     int queues = 2;         // HIP queues the batch is split over (1..4); kernel heads/tails overlap
-    int mixed = 1;          // 256x256: row workgroups of one half + column workgroups of the other per launch
+    int mixed = 0;          // 256x256: row workgroups of one half + column workgroups of the other per launch (k_fmixed)
     int chunk = 0;          // >0: finish all iterations on `chunk` slices before the next chunk (single queue)
     int l1_two_state = 0;   // test hook: ADMM_L1 keeps z and w every iteration instead of u only
 };
@@ -92,6 +92,17 @@ hipError_t fused256_run(Fused256*, hipStream_t s, float* z, float* w, float* x, 
                         bool cnc, float dc_c, ProxParams p, const FusedSchedule& sch);
 // one data-consistency step on caller pointers
 hipError_t fused256_dc(Fused256*, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c);
+
+// "split chain" engine for 256x256 (kernels_fused256.hip, k_fcols2): one column chain per thread and
+// slice; R = float | double.  y is [B][256][256] complex in R (float2 / double2 layout).
+template <typename R> struct Fused256S;
+template <typename R> Fused256S<R>* fused256s_create(int Bmax, hipError_t* err);
+template <typename R> void          fused256s_destroy(Fused256S<R>*);
+template <typename R> hipError_t    fused256s_prepare(Fused256S<R>*, hipStream_t s, const void* y, const uint8_t* mask_bank,
+                                                      const int32_t* mask_id, int B);
+template <typename R> hipError_t    fused256s_run(Fused256S<R>*, hipStream_t s, R* z, R* w, R* x, int B, int iters, bool cnc,
+                                                  R dc_c, ProxParamsT<R> p, const FusedSchedule& sch);
+template <typename R> hipError_t    fused256s_dc(Fused256S<R>*, hipStream_t s, const R* z, const R* w, R* x, int B, R dc_c);
 
 // fused 512x512 path (kernels_fused512.hip): same scheme with 32-lane transforms
 struct Fused512;

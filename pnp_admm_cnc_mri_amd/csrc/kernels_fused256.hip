@@ -33,6 +33,10 @@
 namespace pnp {
 
 __device__ c32 g_twf[256];
+__device__ c64 g_twd[256];
+template <typename R> __device__ __forceinline__ const cxT<R>* tw_table();
+template <> __device__ __forceinline__ const c32* tw_table<float>() { return g_twf; }
+template <> __device__ __forceinline__ const c64* tw_table<double>() { return g_twd; }
 
 struct Fused256 {
     int Bmax = 0, np = 0;
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(256) void k_fprepare(const c32* y, const uint8_t* m
 //   [0]=col 0, [1]=col 128, [2q]=col q, [2q+1]=col 256-q   (q = 1..127)
 __device__ __forceinline__ int phi(int k) { return k < 128 ? 2 * k : (k == 128 ? 1 : 513 - 2 * k); }
 
-template <bool INV>
-__device__ __forceinline__ void fft256_head_lds(c32 (&a)[16], const c32* twl, int t) {
+template <bool INV, typename R>
+__device__ __forceinline__ void fft256_head_lds(cxT<R> (&a)[16], const cxT<R>* twl, int t) {
     dft16<INV>(a);
 #pragma unroll
     for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twl[t * k]);
@@ -104,8 +108,8 @@ constexpr int RP = 272;    // staging pitch (c32) of a row in LDS: 272 % 32 == 1
 constexpr int XP = 289;    // exchange region per 16-lane group, runs of 17 (289 % 32 == 1)
 
 // 16x16 transpose between the lanes of a group; region = this group's XP-sized LDS area
-template <bool INV>
-__device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32* twl, c32* region, int t) {
+template <bool INV, typename R>
+__device__ __forceinline__ void row_fft256(cxT<R> (&a)[16], const cxT<R>* twl, cxT<R>* region, int t) {
     fft256_head_lds<INV>(a, twl, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) region[k * 17 + t] = a[k];
@@ -119,23 +123,28 @@ __device__ __forceinline__ void row_fft256(c32 (&a)[16], const c32* twl, c32* re
 // PROX: see fused_pointwise.h
 constexpr int ROWS_LDS = 16 * XP + 256;      // c32 elements of LDS the row body needs
 
-template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__device__ __forceinline__ void frows_body(const FRowArgs& p, const int bid, c32* lds) {
+template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__device__ __forceinline__ void frows_body(const FRowArgsT<R>& p, const int bid, cxT<R>* lds) {
+    using C = cxT<R>;
+    struct alignas(16) U16 { char b[16]; };              // one 16-byte global / LDS access
+    constexpr int EPU = 16 / (int)sizeof(C);             // elements per access: 2 (float) or 1 (double)
+    constexpr int UPR = 256 / EPU;                       // accesses per row
+    constexpr int NU = 16 * UPR / 256;                   // accesses per thread for the block's 16 rows
     const int tid = threadIdx.x, g = tid >> 4, t = tid & 15;
-    c32* twl = lds + 16 * XP;                  // W256 table (read where used, not held in VGPRs)
-    twl[tid] = g_twf[tid];
+    C* twl = lds + 16 * XP;                    // W256 table (read where used, not held in VGPRs)
+    twl[tid] = tw_table<R>()[tid];
     const int pair = bid >> 4, r0 = (bid & 15) * 16;
     const int sa = 2 * pair, sb = sa + 1;
     const bool has_b = sb < p.B;
-    c32 a[16];
-    c32* Tt = p.T + (size_t)pair * 65536 + (size_t)r0 * 256;     // this block's 16 rows, contiguous
+    C a[16];
+    C* Tt = p.T + (size_t)pair * 65536 + (size_t)r0 * 256;       // this block's 16 rows, contiguous
 
     if (HAS_INV) {
-        const float4* src = reinterpret_cast<const float4*>(Tt);
+        const U16* src = reinterpret_cast<const U16*>(Tt);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 7, c2 = idx & 127;
-            *reinterpret_cast<float4*>(&lds[row * RP + 2 * c2]) = src[idx];
+        for (int i = 0; i < NU; ++i) {
+            const int idx = tid + 256 * i, row = idx / UPR, c2 = idx % UPR;
+            *reinterpret_cast<U16*>(&lds[row * RP + EPU * c2]) = src[idx];
         }
         __syncthreads();
 #pragma unroll
@@ -164,19 +173,19 @@ __device__ __forceinline__ void frows_body(const FRowArgs& p, const int bid, c32
 #pragma unroll
         for (int j = 0; j < 16; ++j) lds[g * RP + phi(t + 16 * j)] = a[j];
         __syncthreads();
-        float4* dst = reinterpret_cast<float4*>(Tt);
+        U16* dst = reinterpret_cast<U16*>(Tt);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 7, c2 = idx & 127;
-            dst[idx] = *reinterpret_cast<const float4*>(&lds[row * RP + 2 * c2]);
+        for (int i = 0; i < NU; ++i) {
+            const int idx = tid + 256 * i, row = idx / UPR, c2 = idx % UPR;
+            dst[idx] = *reinterpret_cast<const U16*>(&lds[row * RP + EPU * c2]);
         }
     }
 }
 
-template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__global__ __launch_bounds__(256) void k_frows(FRowArgs p) {
-    __shared__ __attribute__((aligned(16))) c32 lds[ROWS_LDS];
-    frows_body<HAS_INV, PROX, HAS_FWD, WRITE_X>(p, blockIdx.x, lds);
+template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__global__ __launch_bounds__(256) void k_frows(FRowArgsT<R> p) {
+    __shared__ __attribute__((aligned(16))) cxT<R> lds[ROWS_LDS];
+    frows_body<R, HAS_INV, PROX, HAS_FWD, WRITE_X>(p, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -191,8 +200,8 @@ struct FColArgs {
 
 constexpr int CP = 257;     // exchange region (c32) per column group: 514 dwords % 64 == 2
 
-template <bool INV>
-__device__ __forceinline__ void col_exchange(c32 (&a)[16], c32* region, int t) {
+template <bool INV, typename R>
+__device__ __forceinline__ void col_exchange(cxT<R> (&a)[16], cxT<R>* region, int t) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) region[k * 16 + t] = a[k];
     __syncthreads();
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fmixed(FRowArgs pr, FColArgs pc, int nR
         const int rest = b - full * 25;                  // leftovers of the longer kind
         if (nR > full * 16) rid = full * 16 + rest; else cid = full * 9 + rest;
     }
-    if (rid >= 0) { if (rid < nR) frows_body<HAS_INV, PROX, HAS_FWD, WRITE_X>(pr, rid, lds); }
+    if (rid >= 0) { if (rid < nR) frows_body<float, HAS_INV, PROX, HAS_FWD, WRITE_X>(pr, rid, lds); }
     else if (cid < nC) fcols_body(pc, cid, lds);
 }
 
@@ -348,7 +357,7 @@ hipError_t fused256_prepare(Fused256* f, hipStream_t s, const float2* y, const u
 
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 static hipError_t launch_frows(hipStream_t s, int np, const FRowArgs& a) {
-    hipLaunchKernelGGL((k_frows<HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_frows<float, HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -503,6 +512,275 @@ hipError_t fused256_dc(Fused256* f, hipStream_t s, const float* z, const float* 
     if (e == hipSuccess) e = launch_frows<true, 0, false, true>(s, np, a);
     return e;
 }
+
+
+// ==========================================================================================
+// "Split chain" column kernel and the engine built on it (float and double).
+//
+// The two-slice unpack commutes with the column transform (fft16.h, "split chains"), so each
+// thread runs the whole column chain  FFT -> blend -> inverse FFT  of ONE slice on 16 values and
+// the partner slice lives in the neighbouring lane (lane ^ 1, one DPP move per register):
+//   * per thread 16 complex values instead of P[16] and Q[16]  -> half the data registers, and the
+//     blend operands are one complex value per point instead of a float4: this is what makes a
+//     double-precision instance fit, and it lifts the float instance to 4 waves per SIMD;
+//   * lane s of a pair loads / stores the `s` half of each 2-element {C[r][k2], C[r][256-k2]}
+//     group, so a wave instruction still covers whole 128-byte (float) / 256-byte (double) row
+//     segments of 8 column pairs.
+// ==========================================================================================
+__device__ __forceinline__ float dpp_swap1(float v) {              // value of lane ^ 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double dpp_swap1(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0xB1, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename R> __device__ __forceinline__ cxT<R> dpp_swap1(cxT<R> v) { return mk<R>(dpp_swap1(v.x), dpp_swap1(v.y)); }
+
+template <typename R>
+struct FCol2Args {
+    cxT<R>* T;
+    const cxT<R>* Yh;
+    const uint32_t* Mh;
+    R c;
+};
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_fprepare2(const cxT<R>* y, const uint8_t* mask_bank, const int32_t* mask_id,
+                                                   cxT<R>* Yh, uint32_t* Mh, int B) {
+    __shared__ int nib[256];
+    const int tid = threadIdx.x, j = tid >> 4, t = tid & 15;
+    const int k2 = blockIdx.x, pair = blockIdx.y, k1 = t + 16 * j;
+    int code[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int sl = 2 * pair + s;
+        cxT<R> yh = mk<R>((R)0, (R)0);
+        if (sl < B) {
+            const int mid = mask_id ? mask_id[sl] : 0;
+            hermitian_entry_t<R>(y + (size_t)sl * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh, code[s]);
+        }
+        Yh[yh2_index(pair, k2, j, t, s)] = yh;
+    }
+    nib[tid] = code[0] | (code[1] << 2);
+    __syncthreads();
+    if (tid < 32) {
+        const int tt = tid & 15, s = tid >> 4;
+        uint32_t v = 0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v |= (uint32_t)((nib[jj * 16 + tt] >> (2 * s)) & 3) << (2 * jj);
+        Mh[mh2_index(pair, k2, tt, s)] = v;
+    }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_fcols2(FCol2Args<R> p) {
+    using C = cxT<R>;
+    __shared__ __attribute__((aligned(16))) C lds[COLS_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = lane & 1, kl = (lane >> 1) & 7, t = 4 * wv + (lane >> 4);
+    const int pair = blockIdx.x / F2_TILES, m = blockIdx.x % F2_TILES;
+    const bool self = (m == F2_TILES - 1);
+    const bool valid = self ? (kl < 2) : (8 * m + kl >= 1);
+    // element this lane moves: half `s` of the {column k2, column 256-k2} group (physical 2 k2 + s);
+    // the self-mirrored columns 0 / 128 are single elements (physical 0 / 1) that both lanes read
+    const int phys = self ? kl : 2 * (8 * m + kl) + s;
+    C* Tp = p.T + (size_t)pair * 65536 + phys;
+    C* twl = lds + 16 * CP;
+    twl[tid] = tw_table<R>()[tid];
+    C a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = valid ? Tp[(t + 16 * j) * 256] : mk<R>((R)0, (R)0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C other = self ? a[j] : dpp_swap1(a[j]);
+        const C pv = s ? other : a[j], qv = s ? a[j] : other;
+        a[j] = s ? unpack_b(pv, qv) : unpack_a(pv, qv);          // this slice's row transform, column k2
+    }
+    C* region = lds + (lane & 15) * CP;
+    __syncthreads();                             // twiddle table visible
+    fft256_head_lds<false>(a, twl, t);
+    col_exchange<false>(a, region, t);
+    fft256_tail<false>(a);                       // a[j] = V_s[k1 = t + 16 j, k2]
+    if (valid) {
+        const size_t tb = (size_t)(m * 4 + wv);
+        const uint32_t code = p.Mh[(size_t)pair * MH2_PAIR + tb * 64 + lane];
+        const C* yhp = p.Yh + (size_t)pair * YH2_PAIR + tb * 16 * 64 + lane;
+        const R ch = (R)0.5 * p.c;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = blend_one(a[j], yhp[j * 64], (int)((code >> (2 * j)) & 3u), p.c, ch);
+    }
+    fft256_head_lds<true>(a, twl, t);
+    col_exchange<true>(a, region, t);
+    fft256_tail<true>(a);                        // column k2 of this slice's blended field
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const C other = dpp_swap1(a[j]);
+        const C xa = s ? other : a[j], xb = s ? a[j] : other;
+        const C o = s ? repack_q(xa, xb) : repack_p(xa, xb);
+        if (valid && !(self && s)) Tp[(t + 16 * j) * 256] = o;
+    }
+}
+
+// engine on the split-chain kernels: sequential rows / columns launches over `queues` HIP queues
+template <typename R>
+struct Fused256S {
+    int Bmax = 0, np = 0;
+    cxT<R>* T = nullptr;
+    cxT<R>* Yh = nullptr;
+    uint32_t* Mh = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+template <typename R>
+void fused256s_destroy(Fused256S<R>* f) {
+    if (!f) return;
+    if (f->T) (void)hipFree(f->T);
+    if (f->Yh) (void)hipFree(f->Yh);
+    if (f->Mh) (void)hipFree(f->Mh);
+    if (f->side) (void)hipStreamDestroy(f->side);
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
+    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+    delete f;
+}
+
+template <typename R>
+Fused256S<R>* fused256s_create(int Bmax, hipError_t* err) {
+    Fused256S<R>* f = new Fused256S<R>();
+    f->Bmax = Bmax;
+    f->np = (Bmax + 1) / 2;
+    hipError_t e = hipMalloc((void**)&f->T, (size_t)f->np * 65536 * sizeof(cxT<R>));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Yh, (size_t)f->np * YH2_PAIR * sizeof(cxT<R>));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)f->np * MH2_PAIR * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        static thread_local c32 hf[256];
+        static thread_local c64 hd[256];
+        for (int m = 0; m < 256; ++m) {
+            const double a = -2.0 * M_PI * (double)m / 256.0;
+            hd[m] = mk<double>(cos(a), sin(a));
+            hf[m] = mk<float>((float)cos(a), (float)sin(a));
+        }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_twf), hf, sizeof(hf));
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_twd), hd, sizeof(hd));
+    }
+    if (e != hipSuccess) {
+        fused256s_destroy(f);
+        *err = e;
+        return nullptr;
+    }
+    *err = hipSuccess;
+    return f;
+}
+
+template <typename R>
+hipError_t fused256s_prepare(Fused256S<R>* f, hipStream_t s, const void* y, const uint8_t* mask_bank,
+                             const int32_t* mask_id, int B) {
+    if (B > f->Bmax) return hipErrorInvalidValue;
+    const int np = (B + 1) / 2;
+    hipLaunchKernelGGL(k_fprepare2<R>, dim3(F_HALF, np), dim3(256), 0, s, reinterpret_cast<const cxT<R>*>(y), mask_bank,
+                       mask_id, f->Yh, f->Mh, B);
+    return hipGetLastError();
+}
+
+template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+static hipError_t launch_frows_t(hipStream_t s, int np, const FRowArgsT<R>& a) {
+    hipLaunchKernelGGL((k_frows<R, HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+template <typename R>
+static hipError_t launch_fcols2(Fused256S<R>* f, hipStream_t s, int pair0, int np, R c) {
+    FCol2Args<R> a;
+    a.T = f->T + (size_t)pair0 * 65536;
+    a.Yh = f->Yh + (size_t)pair0 * YH2_PAIR;
+    a.Mh = f->Mh + (size_t)pair0 * MH2_PAIR;
+    a.c = c;
+    hipLaunchKernelGGL(k_fcols2<R>, dim3(np * F2_TILES), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename R>
+static ProxCoefT<R> to_coef_t(const ProxParamsT<R>& p) {
+    ProxCoefT<R> c;
+    c.thr = p.thr; c.c1 = p.c1; c.c2 = p.c2; c.c3 = p.c3; c.ib = p.ib;
+    return c;
+}
+
+// K iterations on slices [c0, c0 + Bc) enqueued on stream s
+template <typename R>
+static hipError_t run_chunk2(Fused256S<R>* f, hipStream_t s, R* z, R* w, R* x, int c0, int Bc, int iters, int prox, R dc_c,
+                             const ProxParamsT<R>& pp) {
+    const int np = (Bc + 1) / 2, pair0 = c0 / 2;
+    const size_t so = (size_t)c0 * 65536;
+    FRowArgsT<R> a;
+    a.T = f->T + (size_t)pair0 * 65536;
+    a.z_in = z + so; a.w_in = w + so; a.z_out = z + so; a.w_out = w + so; a.x_out = x + so; a.B = Bc;
+    a.scale = (R)(1.0 / 65536.0); a.prox = to_coef_t<R>(pp); a.u_first = 1;
+    hipError_t e = launch_frows_t<R, false, 0, true, false>(s, np, a);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) {
+        e = launch_fcols2<R>(f, s, pair0, np, dc_c);
+        if (e != hipSuccess) break;
+        const bool last = (i == iters - 1);
+        a.u_first = (i == 0);
+        if (prox == 2)      e = last ? launch_frows_t<R, true, 2, false, true>(s, np, a) : launch_frows_t<R, true, 2, true, false>(s, np, a);
+        else if (prox == 1) e = last ? launch_frows_t<R, true, 1, false, true>(s, np, a) : launch_frows_t<R, true, 1, true, false>(s, np, a);
+        else                e = last ? launch_frows_t<R, true, 3, false, true>(s, np, a) : launch_frows_t<R, true, 3, true, false>(s, np, a);
+    }
+    return e;
+}
+
+template <typename R>
+hipError_t fused256s_run(Fused256S<R>* f, hipStream_t s, R* z, R* w, R* x, int B, int iters, bool cnc, R dc_c,
+                         ProxParamsT<R> pp, const FusedSchedule& sch) {
+    if (iters <= 0) return hipSuccess;
+    const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
+    if (sch.queues < 2 || B < 64 || sch.chunk > 0) {
+        int chunk = sch.chunk > 0 ? (sch.chunk & ~1) : B;
+        if (chunk < 2) chunk = 2;
+        hipError_t e = hipSuccess;
+        for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
+            e = run_chunk2<R>(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
+        return e;
+    }
+    // two halves of the batch on two HIP queues: the heads and tails of one half's launches overlap the other's
+    hipError_t e = hipSuccess;
+    if (!f->side) {
+        e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    const int BA = ((B / 2) + 1) & ~1;
+    e = hipEventRecord(f->ev_fork, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(f->side, f->ev_fork, 0);
+    if (e == hipSuccess) e = run_chunk2<R>(f, s, z, w, x, 0, BA, iters, prox, dc_c, pp);
+    if (e == hipSuccess) e = run_chunk2<R>(f, f->side, z, w, x, BA, B - BA, iters, prox, dc_c, pp);
+    if (e == hipSuccess) e = hipEventRecord(f->ev_join, f->side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join, 0);
+    return e;
+}
+
+template <typename R>
+hipError_t fused256s_dc(Fused256S<R>* f, hipStream_t s, const R* z, const R* w, R* x, int B, R dc_c) {
+    const int np = (B + 1) / 2;
+    FRowArgsT<R> a;
+    a.T = f->T; a.z_in = z; a.w_in = w; a.z_out = nullptr; a.w_out = nullptr; a.x_out = x; a.B = B;
+    a.scale = (R)(1.0 / 65536.0); a.prox = ProxCoefT<R>{}; a.u_first = 1;
+    hipError_t e = launch_frows_t<R, false, 0, true, false>(s, np, a);
+    if (e == hipSuccess) e = launch_fcols2<R>(f, s, 0, np, dc_c);
+    if (e == hipSuccess) e = launch_frows_t<R, true, 0, false, true>(s, np, a);
+    return e;
+}
+
+#define PNP_INSTANTIATE_F256S(R)                                                                                     \
+    template Fused256S<R>* fused256s_create<R>(int, hipError_t*);                                                   \
+    template void fused256s_destroy<R>(Fused256S<R>*);                                                               \
+    template hipError_t fused256s_prepare<R>(Fused256S<R>*, hipStream_t, const void*, const uint8_t*, const int32_t*, int); \
+    template hipError_t fused256s_run<R>(Fused256S<R>*, hipStream_t, R*, R*, R*, int, int, bool, R, ProxParamsT<R>, const FusedSchedule&); \
+    template hipError_t fused256s_dc<R>(Fused256S<R>*, hipStream_t, const R*, const R*, R*, int, R);
+PNP_INSTANTIATE_F256S(float)
+PNP_INSTANTIATE_F256S(double)
 
 
 }  // namespace pnp

@@ -155,14 +155,6 @@ class _Job:
         return out, psnr1, info
 
 
-def _result(eng, iter_num):
-    """x of the last iteration; with iter_num = 0 the loop body never runs and the reference returns
-    its initial x = |ifft2(y)| (S4:103, 138), which is the engine's z0."""
-    if iter_num <= 0:
-        return eng.get_state()[0]
-    return eng.x()
-
-
 def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets', testset_name='Set1',
             results='results', save_E=None, device=0, return_info=False, **ADMM_L1_opts):
     """ADMM with L1 prox on the MI355X engine.  Reference: "【1】ADMM_L1.py":29-169."""
@@ -173,7 +165,7 @@ def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets'
                psnr_fmt='{:.2f}')                        # S1:150
     with job.open_engine() as eng:
         eng.admm_l1(iter_num, lambda1, reo)              # S1:111-126, all slices, on device
-        x = _result(eng, iter_num)
+        x = eng.x()                                      # iter_num = 0: the initial x = |ifft2(y)| (S4:103, 138)
         out, _, info = job.finish(eng, x)
     return (out, info) if return_info else out
 
@@ -189,6 +181,6 @@ def ADMM_CNC(mask, noises, images=None, y=None, mask_id=None, testsets='testsets
     job = _Job(mask, noises, 'ADMM_CNC', '_ADMM CNC', images, y, mask_id, testsets, testset_name, results, save_E, device)
     with job.open_engine() as eng:
         eng.admm_cnc(iter_num, alpha, lambda1, reo, b)   # S4:115-132
-        x = _result(eng, iter_num)
+        x = eng.x()                                      # iter_num = 0: the initial x = |ifft2(y)| (S4:103, 138)
         out, _, info = job.finish(eng, x)
     return (out, info) if return_info else out

@@ -1,6 +1,8 @@
-"""fp64 validation context: the same device loops in double.  This is where the north star's
-1e-5 / 0.01 dB bar is met END TO END for the runs fp32 cannot hold (100 CNC iterations with the
-committed, locally expansive presets): the reference itself computes in float64."""
+"""fp64 engine: the same device loops in double.  This is where the north star's 1e-5 / 0.01 dB bar is
+met END TO END for the runs fp32 cannot hold (100 CNC iterations with the committed, locally
+expansive presets): the reference itself computes in float64.  At 256x256 the loops run on the fused
+"split chain" kernels in double (k_frows<double>, k_fcols2<double>); other shapes, and
+set_fast_path(0), use the generic kernels in double."""
 import numpy as np
 import pytest
 
@@ -25,18 +27,21 @@ def test_config1_reference_inputs_f64(P, golden_inputs, golden_admm, known_answe
     img = O.requantise(golden_inputs['gray'])
     mask = golden_inputs['masks']['Q_Random30']
     y = O.synthesize(img, mask.astype(np.float64), golden_inputs['noises'])
-    with P.Engine(256, 256, Bmax=1, precision='f64') as eng:
-        eng.upload(y, mask)
-        eng.init_state()
-        eng.admm_l1(50, 0.1, 0.015)
-        xl = eng.x()[0]
-        eng.init_state()
-        eng.admm_cnc(50, 0.45, 0.5, 0.05, 64)
-        xc = eng.x()[0]
-    assert xl.dtype == np.float64
-    assert rel_l2(xl, golden_admm['l1_random30_it50']) <= 1e-9
-    assert rel_l2(xc, golden_admm['cnc_random30_it50']) <= 1e-9
-    assert abs(xl.sum() - known_answers['l1']['x_sum']) <= 1e-6 and abs(xc.sum() - known_answers['cnc']['x_sum']) <= 1e-6
+    for fast, path in ((1, 'fused'), (0, 'generic')):
+        with P.Engine(256, 256, Bmax=1, precision='f64') as eng:
+            eng.set_fast_path(fast)
+            eng.upload(y, mask)
+            assert eng.path_name == path
+            eng.init_state()
+            eng.admm_l1(50, 0.1, 0.015)
+            xl = eng.x()[0]
+            eng.init_state()
+            eng.admm_cnc(50, 0.45, 0.5, 0.05, 64)
+            xc = eng.x()[0]
+        assert xl.dtype == np.float64
+        assert rel_l2(xl, golden_admm['l1_random30_it50']) <= 1e-9
+        assert rel_l2(xc, golden_admm['cnc_random30_it50']) <= 1e-9
+        assert abs(xl.sum() - known_answers['l1']['x_sum']) <= 1e-6 and abs(xc.sum() - known_answers['cnc']['x_sum']) <= 1e-6
 
 
 @pytest.mark.parametrize('H', [256, 512])
@@ -67,4 +72,47 @@ def test_f64_context_rejects_float_entry_points(P):
         with pytest.raises(PnpError):
             eng.synthesize(np.zeros((1, 256, 256), np.float32), np.zeros((256, 256), np.complex64), np.ones((256, 256), np.uint8))
         eng.upload(np.zeros((1, 256, 256), np.complex128), np.ones((256, 256), np.uint8))
+        assert eng.path_name == 'fused'
+    with P.Engine(512, 512, Bmax=1, precision='f64') as eng:
+        eng.upload(np.zeros((1, 512, 512), np.complex128), np.ones((512, 512), np.uint8))
         assert eng.path_name == 'generic'
+
+
+def test_config2_full_batch_on_the_fused_f64_path(P):
+    """Config 2 as BASELINE.json states it -- 512 slices of 256x256, Q_Random30, S4:176 presets, 100 CNC
+    iterations -- on the fused double-precision path: (a) every slice agrees with the generic double
+    kernels (a different FFT factorisation and data flow) to 1e-10; (b) slices 0, 255 and 511 agree
+    with the float64 oracle to 1e-8, three orders inside the north star's 1e-5; (c) odd batches and a
+    run split into two calls give the same result."""
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    B = 512
+    mask = S.reference_masks()['Q_Random30'].astype(np.uint8)
+    with P.Engine(256, 256, Bmax=B) as e32:                   # measurements synthesised on the device (float path)
+        img, noise = S.batch(0, B)
+        e32.synthesize(img, noise, mask)
+        ys = e32.download_y().astype(np.complex128)
+    res = {}
+    for fast in (1, 0):
+        with P.Engine(256, 256, Bmax=B, precision='f64') as eng:
+            eng.set_fast_path(fast)
+            eng.upload(ys, mask)
+            assert eng.path_name == ('fused' if fast else 'generic')
+            eng.init_state()
+            eng.admm_cnc(100, 0.45, 0.5, 0.05, 64)
+            res[fast] = eng.x()
+            if fast:
+                eng.init_state()
+                eng.admm_cnc(37, 0.45, 0.5, 0.05, 64)
+                eng.admm_cnc(63, 0.45, 0.5, 0.05, 64)
+                assert np.array_equal(eng.x(), res[1])          # resumable: 37 + 63 == 100 iterations, bit for bit
+    num = np.sqrt(((res[1] - res[0]) ** 2).sum(axis=(1, 2)))
+    den = np.sqrt((res[0] ** 2).sum(axis=(1, 2)))
+    assert (num / den).max() <= 1e-10, (num / den).max()
+    for b in (0, 255, 511):
+        ref = O.admm_cnc(ys[b], mask, 100)
+        assert rel_l2(res[1][b], ref) <= 1e-8, (b, rel_l2(res[1][b], ref))
+    with P.Engine(256, 256, Bmax=7, precision='f64') as eng:   # odd batch: the last pair has one slice
+        eng.upload(ys[:7], mask)
+        eng.init_state()
+        eng.admm_cnc(100, 0.45, 0.5, 0.05, 64)
+        assert np.array_equal(eng.x(), res[1][:7])

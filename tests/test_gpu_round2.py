@@ -314,3 +314,32 @@ def test_config3_full_batch_properties(env):
     for b in (0, B - 1):
         ref = O.pnp_admm_cnc(ys[b].astype(np.complex128), mask, denoise, 2, 0.9, 1.35, 0.45, 0.3)
         assert rel_l2(full[b], ref) <= 1e-5, (b, rel_l2(full[b], ref))
+
+
+# ----------------------------------------------------------------------------------------------
+# the float instance of the split-chain column kernel (PNP_FUSED_COLS=2)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('solver', ['cnc', 'l1'])
+def test_split_chain_float_engine_vs_oracle(env, golden_inputs, solver, monkeypatch):
+    """k_fcols2<float> (one column chain per thread and slice, partner slice in lane ^ 1) behind the same
+    C ABI: 5 slices (odd: the last pair holds one), three masks, 10 iterations against the oracle, and
+    the teacher-forced x-update against the default engine."""
+    P = env['P']
+    masks = np.stack([golden_inputs['masks'][k] for k in ('Q_Random30', 'Q_Radial30', 'Q_Cartesian30')]).astype(np.uint8)
+    B = 5
+    mid = (np.arange(B) % 3).astype(np.int32)
+    ys = np.stack([O.synthetic_problem(b, masks[mid[b]])[1] for b in range(B)]).astype(np.complex64)
+    monkeypatch.setenv('PNP_FUSED_COLS', '2')
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.upload(ys, masks, mid)
+        assert eng.path_name == 'fused'
+        eng.init_state()
+        if solver == 'cnc':
+            eng.admm_cnc(10, 0.45, 0.5, 0.05, 64)
+        else:
+            eng.admm_l1(10, 0.1, 0.015)
+        x = eng.x()
+    for b in range(B):
+        y128 = ys[b].astype(np.complex128)
+        ref = O.admm_cnc(y128, masks[mid[b]], 10) if solver == 'cnc' else O.admm_l1(y128, masks[mid[b]], 10)
+        assert rel_l2(x[b], ref) <= 2e-6, (b, rel_l2(x[b], ref))

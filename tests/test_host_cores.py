@@ -85,3 +85,77 @@ def test_cooperative_fft512_structures(tmp_path):
     subprocess.check_call(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'host', 'fft512_emulation.cpp')])
     out = subprocess.check_output([exe]).decode()
     assert out.count('rel err') == 4
+
+
+@pytest.mark.parametrize('real,tol', [('f', 5e-7), ('d', 2e-15)])
+@pytest.mark.parametrize('cnc', [0, 1])
+def test_split_chain_pipeline_matches_oracle(emu, golden_inputs, cnc, real, tol):
+    """The "split chain" formulation of the column step (unpack the two real slices BEFORE the column
+    transform, one chain per slice, repack after: csrc/fft16.h, k_fcols2) with its thread-order tables,
+    in float and in double, against the oracle on float-exact inputs and hyper-parameters (measured:
+    1.7e-7 in float, 3e-16 in double)."""
+    exe = str(emu[1] / 'split_chain_emulation')
+    if not os.path.exists(exe):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'host', 'split_chain_emulation.cpp')])
+    z, w, ys, masks = _problem(golden_inputs)
+    reo = 0.0625                                     # exact in float: 1/(1 + 1/(2 reo)) = 1/9 is rounded identically
+    cdc = np.float32(1.0 / (1.0 + 1.0 / 2.0 / reo))
+    if cnc:
+        alpha, lam, b = 0.5, 0.5, 64
+        prox = tuple(np.float32(v) for v in (alpha * reo * lam, 1 - alpha, alpha, alpha * reo * lam * b, 1.0 / b))
+    else:
+        lam = 0.125
+        prox = tuple(np.float32(v) for v in (reo * lam, 0, 0, 0, 0))
+    d = emu[1]
+    inp, out = str(d / 'in2.bin'), str(d / 'out2.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<iif5f', 1, cnc, cdc, *prox))
+        for a, dt in ((z, np.float32), (w, np.float32), (ys, np.complex64), (masks, np.uint8)):
+            f.write(np.ascontiguousarray(a, dtype=dt).tobytes())
+    subprocess.check_call([exe, inp, out, real])
+    raw = np.fromfile(out, dtype=np.float64).reshape(3, 2, 256, 256)
+    for s in range(2):
+        y128 = ys[s].astype(np.complex128)
+        z64, w64 = z[s].astype(np.float64), w[s].astype(np.float64)
+        # the oracle with the float-rounded data-consistency coefficient the program was given
+        v = z64 - w64
+        X = np.fft.fft2(v)
+        m = masks[s] != 0
+        X[m] = X[m] + float(cdc) * (y128[m] - X[m])
+        xr = np.abs(np.real(np.fft.ifft2(X)))
+        if cnc:
+            zr, wr = O.cnc_step(xr, z64, w64, alpha, lam, reo, b)
+        else:
+            zr, wr = O.l1_step(xr, z64, w64, lam, reo)
+        assert rel_l2(raw[0, s], xr) <= tol, rel_l2(raw[0, s], xr)
+        assert rel_l2(raw[1, s], zr) <= 10 * tol
+        assert np.abs(raw[2, s] - wr).max() <= 10 * tol
+
+
+def test_host_cores_under_address_and_ub_sanitizers(golden_inputs, tmp_path):
+    """SURVEY.md section 5 (race / memory checking): the __host__ __device__ cores and the table index
+    functions (the code the kernels index global memory and LDS with) built with
+    -fsanitize=address,undefined and run through all three emulations: no out-of-bounds index, no
+    signed overflow, no misaligned access on the CPU build (GPU sanitizers are not available on the pool)."""
+    san = ['-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all']
+    host = os.path.join(ROOT, 'tests', 'host')
+    exes = {}
+    for name in ('fused_emulation', 'split_chain_emulation', 'fft512_emulation'):
+        exes[name] = str(tmp_path / name)
+        subprocess.check_call(['g++'] + san + ['-o', exes[name], os.path.join(host, name + '.cpp')])
+    z, w, ys, masks = _problem(golden_inputs)
+    inp = str(tmp_path / 'in.bin')
+    with open(inp, 'wb') as f:
+        f.write(struct.pack('<iif5f', 1, 1, 1.0 / 11.0, 0.01125, 0.55, 0.45, 0.72, 1.0 / 64))
+        for a, dt in ((z, np.float32), (w, np.float32), (ys, np.complex64), (masks, np.uint8)):
+            f.write(np.ascontiguousarray(a, dtype=dt).tobytes())
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    for cmd in ([exes['fused_emulation'], inp, str(tmp_path / 'o1.bin')],
+                [exes['split_chain_emulation'], inp, str(tmp_path / 'o2.bin'), 'f'],
+                [exes['split_chain_emulation'], inp, str(tmp_path / 'o3.bin'), 'd'],
+                [exes['fft512_emulation']]):
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and b'runtime error' not in r.stderr and b'AddressSanitizer' not in r.stderr, r.stderr.decode()[-1500:]
+    a = np.fromfile(str(tmp_path / 'o1.bin'), dtype=np.float32).reshape(3, 2, 256, 256)[0]
+    b = np.fromfile(str(tmp_path / 'o2.bin'), dtype=np.float64).reshape(3, 2, 256, 256)[0]
+    assert rel_l2(a, b) <= 5e-7            # both float formulations give the same x
