@@ -77,6 +77,8 @@ struct pnp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Fused256* fused = nullptr;        // 256 x 256
     Fused512* fused5 = nullptr;       // 512 x 512
+    Slice256* slice = nullptr;        // 256 x 256 slice-resident loops (whole runs; pnp_dc_step stays on `fused`)
+    bool slice_ready = false;
     Fused256S<float>* fs32 = nullptr;   // 256 x 256 "split chain" engine in float (PNP_FUSED_COLS=2) ...
     Fused256S<double>* fs64 = nullptr;  // ... and in double: the fast path of an fp64 context
     FusedSchedule sched;              // defaults overridable by PNP_FUSED_* (read at creation) / pnp_set_schedule
@@ -166,7 +168,13 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
         hipError_t fe = hipSuccess;
         if (f64)                                         c->fs64 = fused256s_create<double>(Bmax, &fe);
         else if (H == 256 && env_int("PNP_FUSED_COLS", 1) == 2) c->fs32 = fused256s_create<float>(Bmax, &fe);
-        else if (H == 256)                               c->fused = fused256_create(Bmax, &fe);
+        else if (H == 256) {
+            c->fused = fused256_create(Bmax, &fe);
+            if (c->fused && env_int("PNP_SLICE", 0) == 1) {
+                c->slice = slice256_create(Bmax, &fe);
+                if (!c->slice) { fused256_destroy(c->fused); c->fused = nullptr; }
+            }
+        }
         else                                             c->fused5 = fused512_create(Bmax, &fe);
         if (!c->fused && !c->fused5 && !c->fs32 && !c->fs64) {
             pnp_ctx_destroy(c);
@@ -185,6 +193,7 @@ int pnp_ctx_destroy(pnp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->fused) fused256_destroy(c->fused);
     if (c->fused5) fused512_destroy(c->fused5);
+    if (c->slice) slice256_destroy(c->slice);
     if (c->fs32) fused256s_destroy(c->fs32);
     if (c->fs64) fused256s_destroy(c->fs64);
     void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage, c->ssim_part,
@@ -262,9 +271,14 @@ static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_i
 }
 
 static int prepare_fused(pnp_ctx* c) {
+    c->slice_ready = false;
     if (c->fused) {
         HIPCHK(fused256_prepare(c->fused, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
         c->fused_ready = true;
+        if (c->slice) {
+            HIPCHK(slice256_prepare(c->slice, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
+            c->slice_ready = true;
+        }
     } else if (c->fused5) {
         HIPCHK(fused512_prepare(c->fused5, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
         c->fused_ready = true;
@@ -424,7 +438,8 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, doubl
     }
     const float cdc = dc_coeff(reo);
     if (use_fused(c)) {
-        if (c->fused)       HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        if (c->slice && c->slice_ready) HIPCHK(slice256_run(c->slice, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        else if (c->fused)  HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
         else if (c->fs32)   HIPCHK(fused256s_run<float>(c->fs32, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
         else                HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
     } else {
@@ -683,10 +698,14 @@ int pnp_timer_stop(pnp_ctx* c, float* ms) {
 int pnp_kernels_per_iteration(pnp_ctx* c) {
     if (!c) return 0;
     if (!use_fused(c)) return 3;                      // generic: rows, columns, rows
+    if (c->slice && c->slice_ready) return 0;         // one launch per RUN: the iterations are a loop inside it
     if (c->fs32 || c->fs64) return (c->sched.queues >= 2 && c->B >= 64 && c->sched.chunk <= 0) ? 4 : 2;
     const int q = (c->fused5 || c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
     return 2 * q;                                     // two launches per queue and batched iteration
 }
-const char* pnp_path_name(pnp_ctx* c) { return (c && use_fused(c)) ? "fused" : "generic"; }
+const char* pnp_path_name(pnp_ctx* c) {
+    if (!c || !use_fused(c)) return "generic";
+    return (c->slice && c->slice_ready) ? "slice" : "fused";
+}
 
 }  // extern "C"

@@ -39,8 +39,10 @@ __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
 // to the two-state form.
 // cell: the 4 complex LDS values of these pixels (x in, v out); offa / offb: element offsets of the
 // pixels in slice a / b of the [B][H][W] float arrays.
-template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X, typename R>
-__device__ __forceinline__ void pointwise4(const FRowArgsT<R>& p, cxT<R>* cell, size_t offa, size_t offb, bool has_b) {
+// Off: size_t in the two-launch kernels; the slice-resident kernel passes 32-bit lane offsets on
+// wave-uniform base pointers so that every access is "scalar base + 32-bit lane offset".
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X, typename R, typename Off>
+__device__ __forceinline__ void pointwise4(const FRowArgsT<R>& p, cxT<R>* cell, Off offa, Off offb, bool has_b) {
     using V4 = vec4T<R>;
     R xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
     if (HAS_INV) {

@@ -104,6 +104,14 @@ template <typename R> hipError_t    fused256s_run(Fused256S<R>*, hipStream_t s, 
                                                   R dc_c, ProxParamsT<R> p, const FusedSchedule& sch);
 template <typename R> hipError_t    fused256s_dc(Fused256S<R>*, hipStream_t s, const R* z, const R* w, R* x, int B, R dc_c);
 
+// slice-resident 256x256 path (kernels_slice256.hip): one workgroup keeps one slice in registers for a whole run
+struct Slice256;
+Slice256*  slice256_create(int Bmax, hipError_t* err);
+void       slice256_destroy(Slice256*);
+hipError_t slice256_prepare(Slice256*, hipStream_t s, const float2* y, const uint8_t* mask_bank, const int32_t* mask_id, int B);
+hipError_t slice256_run(Slice256*, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc, float dc_c,
+                        ProxParams p, const FusedSchedule& sch);
+
 // fused 512x512 path (kernels_fused512.hip): same scheme with 32-lane transforms
 struct Fused512;
 Fused512*  fused512_create(int Bmax, hipError_t* err);

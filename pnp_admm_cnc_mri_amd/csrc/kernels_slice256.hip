@@ -1,0 +1,519 @@
+// Slice-resident gfx950 kernel for 256x256 slices: a whole ADMM run with the slice ON the compute unit.
+//
+// The two-launch fused path (kernels_fused256.hip) is bound by HBM traffic, and 16 of its 36 N bytes
+// per slice-iteration are the transposed field T going out after the row pass and coming back for
+// the column pass.  A CU of MI355X has a 512 KiB vector register file and 160 KiB of LDS: one REAL
+// 256x256 slice (256 KiB as 128 packed complex rows, or as 128 half-plane complex columns) fits in
+// the registers of a 1024-thread workgroup (64 VGPRs per thread), and LDS is large enough to turn
+// rows into columns in two passes.  So here ONE workgroup owns ONE slice for all iterations of a
+// run and T never exists in memory:
+//
+//   per iteration and slice:  z, w read + written (16 N bytes; 8 N for ADMM_L1's single-state form),
+//                             Hermitian measurement table read (4 N)              = 20 N (12 N) bytes
+//
+//   rows(first)                 v = z - w, row pairs (2r, 2r+1) packed as one complex row, 16-lane FFT-256
+//   repeat iters times:
+//     T1  row form -> column form through LDS (2 passes), real-to-complex unpack on the way (slice_layout.h)
+//     columns                   FFT-256 -> Hermitian blend against Yh / Mh -> inverse FFT-256
+//                               (127 half-plane columns + the packed column {k2 = 0, k2 = 128})
+//     T2  column form -> row form, complex-to-real repack on the way
+//     rows                      inverse FFT-256 -> x = |re|, |im| / N -> L1 / CNC z-update + dual update
+//                               -> v = z - w -> FFT-256          (S4:119-132; the last one writes x instead)
+//
+// Row and column phases are wave-local (a 16-lane transform group never leaves its wave, each wave
+// has its own LDS region), so the 16 waves of the workgroup drift apart and cover each other's HBM
+// latency; only the two transpositions are workgroup barriers.  Same arithmetic cores as the fused
+// path (fft16.h, fused_pointwise.h); index maps verified on the CPU by tests/host/slice_resident_emulation.cpp.
+#include "internal.h"
+#include "fused_layout.h"
+#include "slice_layout.h"
+#include "fused_pointwise.h"
+#include <math.h>
+
+namespace pnp {
+
+__device__ c32 g_tws[256];
+
+struct SliceArgs {
+    float* z;                 // [B][256][256] state, updated in place
+    float* w;
+    float* x;                 // written by the last iteration
+    const c32* Yh;            // [B] x YH3_SLICE
+    const uint32_t* Mh;       // [B] x MH3_SLICE
+    const c32* Ys;            // [B][256]   k2 = 128
+    const uint32_t* Ms;       // [B][16]
+    int B, iters;
+    float scale, c;
+    ProxCoef prox;
+};
+
+constexpr int WREG = 4 * 272;                 // complex elements of a wave's private LDS region: 4 transform groups x (16 runs of 17)
+constexpr int SL_LDS = 16 * WREG + 256;       // 16 wave regions (the transposition buffer aliases them) + W256 table
+
+// wave-synchronous ordering of LDS traffic: a wave's LDS instructions execute in order, so no
+// s_barrier is needed between lanes of one wave -- only the compiler has to keep the order
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Hides a lane-dependent value from loop-invariant code motion: without it hipcc precomputes the
+// ~100 LDS / table addresses of all phases before the iteration loop and spills them.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// Global memory goes through buffer instructions: a 128-bit descriptor per array in SGPRs, a wave-uniform
+// byte offset in an SGPR (soffset) and ONE 32-bit lane offset register (voffset).  With plain pointers
+// hipcc folds "uniform base + uniform row offset + lane offset" into a 64-bit per-lane address per access
+// (2 VGPRs each, ~80 in the row phase) and spills.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t bufrsrc;
+__device__ __forceinline__ bufrsrc make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// State loads carry sc1 (aux bit 4): they are served by L2, not by the CU's vector L1.  The loop re-reads
+// z / w that THIS workgroup stored one iteration earlier inside the same launch, and a store does not
+// refresh a line the L1 still holds from the earlier load (seen on the GPU as a few stale 64-byte sectors).
+__device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]) {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
+    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+}
+// Stores fold the wave-uniform offset into the lane offset (soffset = 0), on purpose: a 16-byte buffer store
+// reads its data registers over several cycles, and a VALU write to them right behind the store needs wait
+// states.  hipcc inserts them only when soffset is NOT an SGPR (the rule of older ISAs); with an SGPR soffset
+// it let "buffer_store_dwordx4 v[28:31] ...; v_mov_b32 v28, ..." through, and on gfx950 the store then
+// wrote the NEW v28 for the last 4 lanes of each 16 -- seen as sporadic wrong z values.
+__device__ __forceinline__ void st4(bufrsrc r, int voff, int soff, const float (&v)[4]) {
+    u32x4 q;
+    q.x = __float_as_uint(v[0]); q.y = __float_as_uint(v[1]); q.z = __float_as_uint(v[2]); q.w = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, 0);
+}
+__device__ __forceinline__ c32 ldc(bufrsrc r, int voff, int soff) {
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return mk<float>(__uint_as_float(q.x), __uint_as_float(q.y));
+}
+struct SliceBufs {
+    bufrsrc z, w, x;          // the slice's [256][256] float arrays
+    bufrsrc yh, mh, ys, ms;   // its operand tables
+};
+
+// Forces a value to be computed HERE: LLVM otherwise sinks the pure unpack arithmetic of the transposition
+// below the following barrier to its first use and keeps (spills) the 64 raw registers it was computed from.
+__device__ __forceinline__ void pin(c32& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+// keeps memory operations on their side (limits how many loads the scheduler piles up in registers)
+__device__ __forceinline__ void mem_fence_compiler() { asm volatile("" ::: "memory"); }
+// nothing is scheduled across this point: keeps the two register sets' chains from being interleaved
+// (which would double the live temporaries of a 128-VGPR kernel)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+__device__ __forceinline__ float dpp_lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ c32 dpp_lane_xor1(c32 v) { return mk<float>(dpp_lane_xor1(v.x), dpp_lane_xor1(v.y)); }
+
+// dft16 of fft16.h, operation for operation, with the eight radix-4 butterflies kept apart by
+// scheduling barriers: hipcc otherwise interleaves them for ILP and needs ~65 temporaries; with four
+// waves per SIMD the other waves provide the parallelism, and this kernel has 64 registers of working space
+template <bool INV>
+__device__ __forceinline__ void dft16_lp(c32 (&a)[16]) {
+    const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) { dft4<INV>(a[n0], a[n0 + 4], a[n0 + 8], a[n0 + 12]); sched_fence(); }
+    a[1 + 4] = tmul<INV>(a[1 + 4], mk<float>(C1, -S1));
+    a[1 + 8] = tmul<INV>(a[1 + 8], mk<float>(H, -H));
+    a[1 + 12] = tmul<INV>(a[1 + 12], mk<float>(S1, -C1));
+    a[2 + 4] = tmul<INV>(a[2 + 4], mk<float>(H, -H));
+    a[2 + 8] = rot<INV>(a[2 + 8]);
+    a[2 + 12] = tmul<INV>(a[2 + 12], mk<float>(-H, -H));
+    a[3 + 4] = tmul<INV>(a[3 + 4], mk<float>(S1, -C1));
+    a[3 + 8] = tmul<INV>(a[3 + 8], mk<float>(-H, -H));
+    a[3 + 12] = tmul<INV>(a[3 + 12], mk<float>(-C1, S1));
+    sched_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) { dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]); sched_fence(); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const c32 tmp = a[4 * i + j];
+            a[4 * i + j] = a[4 * j + i];
+            a[4 * j + i] = tmp;
+        }
+}
+
+// 16-lane FFT-256 on a[16] (lane t holds index t + 16 j), exchange through the group's region
+template <bool INV>
+__device__ __forceinline__ void group_fft256(c32 (&a)[16], const c32* twl, c32* region, int t) {
+    dft16_lp<INV>(a);
+    // twl is stored per lane: twl[16 t + k] = W256^(t k): one address register + immediate offsets,
+    // fetched after the butterflies (not piled up in registers before them)
+    mem_fence_compiler();
+    const c32* tw = twl + 16 * t;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a[k] = tmul<INV>(a[k], tw[k]);
+    mem_fence_compiler();
+#pragma unroll
+    for (int k = 8; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) region[k * 17 + t] = a[k];
+    wave_sync();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) a[n] = region[t * 17 + n];
+    wave_sync();
+    dft16_lp<INV>(a);
+}
+
+// ------------------------------------------------------------------------------------------
+// rows: one register set = the share of 4 row pairs (8 image rows) this wave owns
+// ------------------------------------------------------------------------------------------
+// Pointwise phase of ONE row pair for 4 consecutive pixels per lane; the arithmetic of pointwise4
+// (fused_pointwise.h) operation for operation, with re = image row 2rr and im = row 2rr + 1 of the same slice.
+// cell: the 4 complex LDS values (x in, v out); voff = 16 lane; soff = byte offset of row 2rr in the slice.
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32* cell,
+                                                  int voff, int soff) {
+    const int soffb = soff + 1024;
+    float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
+    if (HAS_INV) {
+        const float4 c01 = *reinterpret_cast<const float4*>(cell);
+        const float4 c23 = *reinterpret_cast<const float4*>(cell + 2);
+        xa[0] = fabsf(c01.x) * scale; xb[0] = fabsf(c01.y) * scale;
+        xa[1] = fabsf(c01.z) * scale; xb[1] = fabsf(c01.w) * scale;
+        xa[2] = fabsf(c23.x) * scale; xb[2] = fabsf(c23.y) * scale;
+        xa[3] = fabsf(c23.z) * scale; xb[3] = fabsf(c23.w) * scale;
+    }
+    float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+    if (PROX == 3) {                                   // ADMM_L1 single-state form: the w buffer carries u = x + w_old
+        ld4(b.w, voff, soff, wa);
+        ld4(b.w, voff, soffb, wb);
+        float ua[4], ub[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!u_first) {
+                wa[q] = wa[q] - soft_thr(wa[q], pc.thr);
+                wb[q] = wb[q] - soft_thr(wb[q], pc.thr);
+            }
+            ua[q] = xa[q] + wa[q];
+            ub[q] = xb[q] + wb[q];
+            za[q] = soft_thr(ua[q], pc.thr); wa[q] = ua[q] - za[q];
+            zb[q] = soft_thr(ub[q], pc.thr); wb[q] = ub[q] - zb[q];
+        }
+        if (HAS_FWD) {
+            st4(b.w, voff, soff, ua);
+            st4(b.w, voff, soffb, ub);
+        } else {
+            st4(b.z, voff, soff, za); st4(b.w, voff, soff, wa);
+            st4(b.z, voff, soffb, zb); st4(b.w, voff, soffb, wb);
+        }
+    }
+    if ((PROX != 0 && PROX != 3) || !HAS_INV) {
+        ld4(b.z, voff, soff, za); ld4(b.w, voff, soff, wa);
+        ld4(b.z, voff, soffb, zb); ld4(b.w, voff, soffb, wb);
+    }
+    if (PROX == 1 || PROX == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], pc); prox_l1_pt(xb[q], zb[q], wb[q], pc); }
+            else           { prox_cnc_pt(xa[q], za[q], wa[q], pc); prox_cnc_pt(xb[q], zb[q], wb[q], pc); }
+        }
+        st4(b.z, voff, soff, za); st4(b.w, voff, soff, wa);
+        st4(b.z, voff, soffb, zb); st4(b.w, voff, soffb, wb);
+    }
+    if (WRITE_X) {
+        st4(b.x, voff, soff, xa);
+        st4(b.x, voff, soffb, xb);
+    }
+    if (HAS_FWD) {
+        *reinterpret_cast<float4*>(cell) = make_float4(za[0] - wa[0], zb[0] - wb[0], za[1] - wa[1], zb[1] - wb[1]);
+        *reinterpret_cast<float4*>(cell + 2) = make_float4(za[2] - wa[2], zb[2] - wb[2], za[3] - wa[3], zb[3] - wb[3]);
+    }
+}
+
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__device__ __forceinline__ void row_set(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32 (&a)[16], int set,
+                                        c32* wreg, const c32* twl, int wv, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    c32* region = wreg + g * 272;
+    if (HAS_INV) {
+        group_fft256<true>(a, twl, region, t);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];           // natural order: element n of row pair g
+        wave_sync();
+    }
+    // the wave's 4 row pairs: 4 consecutive pixels per lane, one full 1-KiB image row per access
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int soff = (2 * (64 * set + 4 * wv + i)) * 1024;           // wave-uniform: byte offset of image row 2rr
+        pointwise_rowpair<HAS_INV, PROX, HAS_FWD, WRITE_X>(b, pc, scale, u_first, wreg + i * 272 + 4 * lane, 16 * lane, soff);
+        if (i == 1) mem_fence_compiler();            // two row pairs' loads in flight at a time (8 x 16 B per lane)
+    }
+    if (HAS_FWD) {
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = region[t + 16 * j];
+        wave_sync();
+        group_fft256<false>(a, twl, region, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// transpositions (workgroup-wide, two passes each); slots: slice_layout.h
+// ------------------------------------------------------------------------------------------
+// The 8 registers of a row-form set that cross in pass P, with their slots (sl_pass / sl_slot of
+// slice_layout.h, k = t + 16 j).  Register indices must be literals (register arrays), so the lists
+// are spelled out: X(ja, jb, slot) handles register ja -- or, in lane 0 of a group, register jb:
+// k = 128 and k = 192 sit in lane 0 of j = 8 / 12 and belong to the other pass than the rest of their register.
+#define SL_PASS0_REGS(X, t)                                                                       \
+    X(0, 0, (t)) X(1, 1, (t) + 16) X(2, 2, (t) + 32) X(3, 3, (t) + 48)                              \
+    X(12, 8, ((t) ? SL_M + 64 - (t) : SL_M))                                                      \
+    X(13, 13, SL_M + 48 - (t)) X(14, 14, SL_M + 32 - (t)) X(15, 15, SL_M + 16 - (t))
+#define SL_PASS1_REGS(X, t)                                                                       \
+    X(4, 4, (t)) X(5, 5, (t) + 16) X(6, 6, (t) + 32) X(7, 7, (t) + 48)                              \
+    X(8, 12, ((t) ? SL_M + 64 - (t) : SL_M))                                                      \
+    X(9, 9, SL_M + 48 - (t)) X(10, 10, SL_M + 32 - (t)) X(11, 11, SL_M + 16 - (t))
+
+template <int P>
+__device__ __forceinline__ void t1_pass(const c32 (&F0)[16], const c32 (&F1)[16], c32 (&G)[16], c32* buf, int wv, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    {
+        c32* r0 = buf + (4 * wv + g) * SL_P;              // row pair of set 0; set 1 is 64 row pairs further
+        c32* r1 = r0 + 64 * SL_P;
+#define SL_T1_STORE(ja, jb, slot) { r0[slot] = t ? F0[ja] : F0[jb]; r1[slot] = t ? F1[ja] : F1[jb]; }
+        if (P == 0) { SL_PASS0_REGS(SL_T1_STORE, t) } else { SL_PASS1_REGS(SL_T1_STORE, t) }
+#undef SL_T1_STORE
+    }
+    __syncthreads();
+    {
+        const int cc = 4 * wv + g, odd = t & 1;
+        const bool packed = (P == 0 && cc == 0);
+        const c32* col = buf + (t >> 1) * SL_P + cc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const c32 d = col[8 * j * SL_P], m = col[8 * j * SL_P + SL_M];
+            const c32 va = packed ? mk<float>(d.x, m.x) : unpack_a(d, m);
+            const c32 vb = packed ? mk<float>(d.y, m.y) : unpack_b(d, m);
+            G[j] = odd ? vb : va;
+            pin(G[j]);                            // unpack as the values arrive: raw pairs must not pile up across the barrier
+            if ((j & 3) == 3) sched_fence();
+        }
+    }
+    __syncthreads();
+}
+
+template <int P>
+__device__ __forceinline__ void t2_pass(const c32 (&G)[16], c32 (&F0)[16], c32 (&F1)[16], c32* buf, int wv, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    {
+        const int cc = 4 * wv + g, odd = t & 1;
+        const bool packed = (P == 0 && cc == 0);
+        c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const c32 other = dpp_lane_xor1(G[j]);
+            const c32 ue = odd ? other : G[j], uo = odd ? G[j] : other;
+            const c32 dp = packed ? mk<float>(ue.x, uo.x) : repack_p(ue, uo);
+            const c32 dq = packed ? mk<float>(ue.y, uo.y) : repack_q(ue, uo);
+            col[8 * j * SL_P] = odd ? dq : dp;
+            if ((j & 3) == 3) sched_fence();
+        }
+    }
+    __syncthreads();
+    {
+        const c32* r0 = buf + (4 * wv + g) * SL_P;
+        const c32* r1 = r0 + 64 * SL_P;
+#define SL_T2_LOAD(ja, jb, slot) { F0[ja] = r0[slot]; F1[ja] = r1[slot]; }      /* lane 0 of a group: fixed up after pass 1 */
+        if (P == 0) { SL_PASS0_REGS(SL_T2_LOAD, t) } else { SL_PASS1_REGS(SL_T2_LOAD, t) }
+        if (P == 1) {     // lane 0 received k = 128 in register 12 (pass 0) and k = 192 in register 8 (pass 1): swap them
+            const c32 a0 = F0[8], a1 = F1[8];
+            F0[8] = t ? a0 : F0[12]; F0[12] = t ? F0[12] : a0;
+            F1[8] = t ? a1 : F1[12]; F1[12] = t ? F1[12] : a1;
+        }
+#undef SL_T2_LOAD
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// columns: one register set = the share of 4 columns this wave owns
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void col_set(const SliceBufs& b, float cdc, c32 (&a)[16], int set, c32* wreg, const c32* twl, int wv, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    c32* region = wreg + g * 272;
+    group_fft256<false>(a, twl, region, t);                       // a[j] = spectrum at k1 = t + 16 j, k2 = c
+    mem_fence_compiler();                                         // operand loads start here, not before the transform
+    // table rows are in thread order: wave-uniform byte offset + 8 (4) bytes per lane
+    const int ybase = ((set * 16) * 16 + wv) * 64 * 8;            // yh3_index(.., set, j = 0, wv, lane = 0) in bytes; + j * 8192
+    const uint32_t code = __builtin_amdgcn_raw_buffer_load_b32(b.mh, 4 * lane, (set * 16 + wv) * 64 * 4, 0);
+    const float ch = 0.5f * cdc;
+    if (set == 0 && wv == 0 && g == 0) {
+        // packed column: a = A + i B, A / B = spectra of the real columns k2 = 0 / 128; split with the mirror k1 -> -k1
+#pragma unroll
+        for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];
+        wave_sync();
+        const uint32_t code_b = __builtin_amdgcn_raw_buffer_load_b32(b.ms, 4 * t, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const c32 gm = region[(256 - (t + 16 * j)) & 255];
+            const c32 A = blend_one(unpack_a(a[j], gm), ldc(b.yh, 8 * lane, ybase + j * 8192), (int)((code >> (2 * j)) & 3u), cdc, ch);
+            const c32 Bv = blend_one(unpack_b(a[j], gm), ldc(b.ys, 8 * t, 128 * j), (int)((code_b >> (2 * j)) & 3u), cdc, ch);
+            a[j] = repack_p(A, Bv);
+        }
+        wave_sync();
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = blend_one(a[j], ldc(b.yh, 8 * lane, ybase + j * 8192), (int)((code >> (2 * j)) & 3u), cdc, ch);
+        mem_fence_compiler();                                     // 8 operand loads (16 registers) in flight at a time
+#pragma unroll
+        for (int j = 8; j < 16; ++j) a[j] = blend_one(a[j], ldc(b.yh, 8 * lane, ybase + j * 8192), (int)((code >> (2 * j)) & 3u), cdc, ch);
+    }
+    group_fft256<true>(a, twl, region, t);                        // column c of the blended field, unnormalised
+}
+
+// ------------------------------------------------------------------------------------------
+// PROX: 1 L1 (z and w), 2 CNC, 3 L1 single-state (see fused_pointwise.h)
+// ------------------------------------------------------------------------------------------
+template <int PROX>
+__global__ __launch_bounds__(1024) void k_slice(SliceArgs p) {
+    __shared__ __attribute__((aligned(16))) c32 lds[SL_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index as a scalar: bases below stay in SGPRs
+    c32* twl = lds + 16 * WREG;
+    if (tid < 256) twl[tid] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k)
+    c32* wreg = lds + wv * WREG;
+    __syncthreads();
+    for (int slice = blockIdx.x; slice < p.B; slice += gridDim.x) {
+        const size_t so = (size_t)slice * 65536;
+        SliceBufs b;
+        b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + so, 65536 * 4);
+        b.yh = make_rsrc(p.Yh + (size_t)slice * YH3_SLICE, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
+        b.ys = make_rsrc(p.Ys + (size_t)slice * 256, 256 * 8); b.ms = make_rsrc(p.Ms + (size_t)slice * 16, 16 * 4);
+        c32 F0[16], F1[16];
+        row_set<false, 0, true, false>(b, p.prox, p.scale, 1, F0, 0, wreg, twl, wv, opaque(lane));
+        row_set<false, 0, true, false>(b, p.prox, p.scale, 1, F1, 1, wreg, twl, wv, opaque(lane));
+        for (int it = 0; it < p.iters; ++it) {
+            c32 G0[16], G1[16];
+            __syncthreads();                      // every wave is done with its private region: the buffer aliases them
+            t1_pass<0>(F0, F1, G0, lds, wv, opaque(lane));
+            t1_pass<1>(F0, F1, G1, lds, wv, opaque(lane));
+            col_set(b, p.c, G0, 0, wreg, twl, wv, opaque(lane));
+            col_set(b, p.c, G1, 1, wreg, twl, wv, opaque(lane));
+            __syncthreads();
+            t2_pass<0>(G0, F0, F1, lds, wv, opaque(lane));
+            t2_pass<1>(G1, F0, F1, lds, wv, opaque(lane));
+            const int u_first = (it == 0);
+            if (it + 1 < p.iters) {
+                row_set<true, PROX, true, false>(b, p.prox, p.scale, u_first, F0, 0, wreg, twl, wv, opaque(lane));
+                row_set<true, PROX, true, false>(b, p.prox, p.scale, u_first, F1, 1, wreg, twl, wv, opaque(lane));
+            } else {
+                row_set<true, PROX, false, true>(b, p.prox, p.scale, u_first, F0, 0, wreg, twl, wv, opaque(lane));
+                row_set<true, PROX, false, true>(b, p.prox, p.scale, u_first, F1, 1, wreg, twl, wv, opaque(lane));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// operand tables (once per uploaded problem): one block per (k2 = 0..128, slice)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
+                                                  c32* Yh, uint32_t* Mh, c32* Ys, uint32_t* Ms) {
+    __shared__ int codes[256];
+    const int k1 = threadIdx.x, j = k1 >> 4, t = k1 & 15;
+    const int k2 = blockIdx.x, slice = blockIdx.y;
+    const int mid = mask_id ? mask_id[slice] : 0;
+    c32 yh;
+    int code;
+    hermitian_entry_t<float>(y + (size_t)slice * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh, code);
+    codes[k1] = code;
+    const int c = k2 & 127, set = c >> 6, wv = (c & 63) >> 2, lane = 16 * (c & 3) + t;
+    if (k2 < 128) Yh[yh3_index(slice, set, j, wv, lane)] = yh;
+    else          Ys[(size_t)slice * 256 + k1] = yh;
+    __syncthreads();
+    if (k1 < 16) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v |= (uint32_t)codes[k1 + 16 * jj] << (2 * jj);
+        if (k2 < 128) Mh[mh3_index(slice, set, wv, 16 * (c & 3) + k1)] = v;
+        else          Ms[slice * 16 + k1] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Slice256 {
+    int Bmax = 0, cus = 0;
+    c32* Yh = nullptr;
+    uint32_t* Mh = nullptr;
+    c32* Ys = nullptr;
+    uint32_t* Ms = nullptr;
+};
+
+void slice256_destroy(Slice256* f) {
+    if (!f) return;
+    if (f->Yh) (void)hipFree(f->Yh);
+    if (f->Mh) (void)hipFree(f->Mh);
+    if (f->Ys) (void)hipFree(f->Ys);
+    if (f->Ms) (void)hipFree(f->Ms);
+    delete f;
+}
+
+Slice256* slice256_create(int Bmax, hipError_t* err) {
+    Slice256* f = new Slice256();
+    f->Bmax = Bmax;
+    hipError_t e = hipMalloc((void**)&f->Yh, (size_t)Bmax * YH3_SLICE * sizeof(c32));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)Bmax * MH3_SLICE * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Ys, (size_t)Bmax * 256 * sizeof(c32));
+    if (e == hipSuccess) e = hipMalloc((void**)&f->Ms, (size_t)Bmax * 16 * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        static thread_local c32 h[256];
+        for (int m = 0; m < 256; ++m) {
+            const double a = -2.0 * M_PI * (double)m / 256.0;
+            h[m] = mk<float>((float)cos(a), (float)sin(a));
+        }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_tws), h, sizeof(h));
+    }
+    if (e == hipSuccess) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) f->cus = prop.multiProcessorCount;
+    }
+    if (e != hipSuccess) {
+        slice256_destroy(f);
+        *err = e;
+        return nullptr;
+    }
+    *err = hipSuccess;
+    return f;
+}
+
+hipError_t slice256_prepare(Slice256* f, hipStream_t s, const float2* y, const uint8_t* mask_bank, const int32_t* mask_id, int B) {
+    if (B > f->Bmax) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sprepare, dim3(129, B), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank, mask_id,
+                       f->Yh, f->Mh, f->Ys, f->Ms);
+    return hipGetLastError();
+}
+
+hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc, float dc_c,
+                        ProxParams pp, const FusedSchedule& sch) {
+    if (iters <= 0) return hipSuccess;
+    SliceArgs a;
+    a.z = z; a.w = w; a.x = x; a.Yh = f->Yh; a.Mh = f->Mh; a.Ys = f->Ys; a.Ms = f->Ms;
+    a.B = B; a.iters = iters; a.scale = 1.0f / 65536.0f; a.c = dc_c;
+    a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
+    // one workgroup per slice; a workgroup fills a compute unit (1024 threads x 128 VGPRs, 138 KiB of LDS)
+    const dim3 grid(B);
+    if (cnc)                    hipLaunchKernelGGL(k_slice<2>, grid, dim3(1024), 0, s, a);
+    else if (sch.l1_two_state)  hipLaunchKernelGGL(k_slice<1>, grid, dim3(1024), 0, s, a);
+    else                        hipLaunchKernelGGL(k_slice<3>, grid, dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace pnp

@@ -140,7 +140,7 @@ def test_host_cores_under_address_and_ub_sanitizers(golden_inputs, tmp_path):
     san = ['-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all']
     host = os.path.join(ROOT, 'tests', 'host')
     exes = {}
-    for name in ('fused_emulation', 'split_chain_emulation', 'fft512_emulation'):
+    for name in ('fused_emulation', 'split_chain_emulation', 'slice_resident_emulation', 'fft512_emulation'):
         exes[name] = str(tmp_path / name)
         subprocess.check_call(['g++'] + san + ['-o', exes[name], os.path.join(host, name + '.cpp')])
     z, w, ys, masks = _problem(golden_inputs)
@@ -153,9 +153,50 @@ def test_host_cores_under_address_and_ub_sanitizers(golden_inputs, tmp_path):
     for cmd in ([exes['fused_emulation'], inp, str(tmp_path / 'o1.bin')],
                 [exes['split_chain_emulation'], inp, str(tmp_path / 'o2.bin'), 'f'],
                 [exes['split_chain_emulation'], inp, str(tmp_path / 'o3.bin'), 'd'],
+                [exes['slice_resident_emulation'], inp, str(tmp_path / 'o4.bin')],
                 [exes['fft512_emulation']]):
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0 and b'runtime error' not in r.stderr and b'AddressSanitizer' not in r.stderr, r.stderr.decode()[-1500:]
     a = np.fromfile(str(tmp_path / 'o1.bin'), dtype=np.float32).reshape(3, 2, 256, 256)[0]
     b = np.fromfile(str(tmp_path / 'o2.bin'), dtype=np.float64).reshape(3, 2, 256, 256)[0]
     assert rel_l2(a, b) <= 5e-7            # both float formulations give the same x
+
+
+@pytest.mark.parametrize('cnc', [0, 1])
+def test_slice_resident_pipeline_matches_oracle(emu, golden_inputs, cnc):
+    """The slice-resident formulation (kernels_slice256.hip): ONE real slice as 128 packed row pairs,
+    real-to-complex unpack inside the two-pass LDS transposition (csrc/slice_layout.h), 127 half-plane
+    columns plus the packed column {0, 128}, Hermitian blend, and the mirrored way back -- emulated
+    thread by thread with the kernel's index maps against the oracle (collisions / holes in the
+    transposition maps make the program exit non-zero)."""
+    exe = str(emu[1] / 'slice_resident_emulation')
+    if not os.path.exists(exe):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'host', 'slice_resident_emulation.cpp')])
+    z, w, ys, masks = _problem(golden_inputs)
+    reo = 0.05
+    cdc = 1.0 / (1.0 + 1.0 / 2.0 / reo)
+    if cnc:
+        alpha, lam, b = 0.45, 0.5, 64
+        prox = (alpha * reo * lam, 1 - alpha, alpha, alpha * reo * lam * b, 1.0 / b)
+    else:
+        lam = 0.1
+        prox = (reo * lam, 0, 0, 0, 0)
+    d = emu[1]
+    for s in range(2):                                  # the program reconstructs slice 0 of its input file
+        order = [s, 1 - s]
+        inp, out = str(d / 'in3.bin'), str(d / 'out3.bin')
+        with open(inp, 'wb') as f:
+            f.write(struct.pack('<iif5f', 1, cnc, cdc, *prox))
+            for a, dt in ((z[order], np.float32), (w[order], np.float32), (ys[order], np.complex64), (masks[order], np.uint8)):
+                f.write(np.ascontiguousarray(a, dtype=dt).tobytes())
+        subprocess.check_call([exe, inp, out])
+        raw = np.fromfile(out, dtype=np.float64).reshape(3, 256, 256)
+        y128 = ys[s].astype(np.complex128)
+        xr = O.dc_step(z[s].astype(np.float64), w[s].astype(np.float64), y128, masks[s], reo)
+        if cnc:
+            zr, wr = O.cnc_step(xr, z[s].astype(np.float64), w[s].astype(np.float64), alpha, lam, reo, b)
+        else:
+            zr, wr = O.l1_step(xr, z[s].astype(np.float64), w[s].astype(np.float64), lam, reo)
+        assert rel_l2(raw[0], xr) <= 2e-6, rel_l2(raw[0], xr)
+        assert rel_l2(raw[1], zr) <= 2e-6
+        assert np.abs(raw[2] - wr).max() <= 2e-6
