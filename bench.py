@@ -9,6 +9,12 @@ One "step" = one batched ADMM iteration (x-update in k-space, CNC z-update, dual
 the 512 slices a GPU holds.  Slices are independent, so N GPUs hold N x 512 different slices
 (weak scaling), run without any data-path collective, and one RCCL gather of x at the end is
 timed separately (`gather_ms`).  Inputs are resident in HBM before the timed region.
+`python bench.py --gpus N` starts its own N rank processes (children of a parent that never
+touches the GPU); under `torch.distributed.run` it takes the ranks it is given.
+
+At 256x256 with a chip-filling batch the K steps of a call are ONE launch of the slice-resident
+kernel (config.path = "slice": a workgroup keeps its slice in registers for all K iterations);
+smaller batches, 512x512 and --precision f64 use the two-launch fused kernels ("fused").
 
 Prints ONE JSON line (rank 0).  `value` = 512-slice batch iterations per second summed over
 ranks = slice-iterations/s / 512.  `roofline.achieved` = 57*N_pix*B*K algorithmic bytes
@@ -269,6 +275,8 @@ def main():
             except Exception:
                 traffic = None
         sched = eng.schedule if eng.path_name == 'fused' else {'queues': 1, 'mixed': 0, 'chunk': 0}
+        if args.generic or eng.path_name == 'generic':
+            sched = {'queues': 1, 'mixed': 0, 'chunk': 0}
         ev_s_per_it = ev_ms * 1e-3 / K
         line = {
             'metric': 'ADMM iterations/sec on 256x256 complex64 slices (batch=512)',
@@ -280,6 +288,7 @@ def main():
                                    % (args.solver.upper(), B, H, W, 'Q_Random30' if H == 256 else 'seeded mask bank of 3',
                                       'S4:176' if args.solver == 'cnc' else 'S1:171'),
                        'slices_per_gpu': B, 'path': eng.path_name, 'precision': args.precision,
+                       # 0 = the iterations of a call are a loop inside ONE launch (slice-resident kernel)
                        'launches_per_iteration': eng.kernels_per_iteration,
                        'queues': sched['queues'], 'mixed_row_col_launches': bool(sched['mixed'])},
             'slice_iterations_per_s': value * B_PER_GPU,
@@ -294,8 +303,9 @@ def main():
                          'traffic_from': traffic_src,
                          'note': 'achieved = 57*H*W*B algorithmic bytes per iteration (SURVEY.md 8d: plain c2c float32 '
                                  'formulation) / HIP-event time per iteration on the kernels\' stream; it exceeds the peak '
-                                 'because the fused kernels move fewer bytes than that formulation (two real slices per '
-                                 'complex FFT, Hermitian half plane, nibble masks).  achieved_measured / frac_measured = '
+                                 'because the kernels move fewer bytes than that formulation (slice-resident path: z, w and the '
+                                 'Hermitian half-plane table only, the transposed field never leaves the compute unit; fused path: '
+                                 'two real slices per complex FFT, Hermitian half plane).  achieved_measured / frac_measured = '
                                  'PMC-measured HBM bytes per iteration (traffic, FETCH_SIZE x2 + WRITE_SIZE) / the same time.'},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -79,6 +79,8 @@ struct pnp_ctx {
     Fused512* fused5 = nullptr;       // 512 x 512
     Slice256* slice = nullptr;        // 256 x 256 slice-resident loops (whole runs; pnp_dc_step stays on `fused`)
     bool slice_ready = false;
+    int slice_min_b = 0;              // batches at least this large run their loops slice-resident
+    bool slice_force = false;
     Fused256S<float>* fs32 = nullptr;   // 256 x 256 "split chain" engine in float (PNP_FUSED_COLS=2) ...
     Fused256S<double>* fs64 = nullptr;  // ... and in double: the fast path of an fp64 context
     FusedSchedule sched;              // defaults overridable by PNP_FUSED_* (read at creation) / pnp_set_schedule
@@ -170,7 +172,15 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
         else if (H == 256 && env_int("PNP_FUSED_COLS", 1) == 2) c->fs32 = fused256s_create<float>(Bmax, &fe);
         else if (H == 256) {
             c->fused = fused256_create(Bmax, &fe);
-            if (c->fused && env_int("PNP_SLICE", 0) == 1) {
+            // Slice-resident loops: one workgroup (= one compute unit) per slice, so they pay off once the batch
+            // fills the chip; small batches stay on the two-launch path, which spreads a slice over many CUs.
+            // PNP_SLICE=0 never, =1 always, unset: batches that fill the chip's compute units in whole rounds
+            // (see slice_pays(); measured on MI355X: 256 slices 0.090 vs 0.100 ms, 512: 0.170 vs 0.205,
+            // 768: 0.241 vs 0.350, 1024: 0.313 vs 0.425 per iteration; 384 -- one and a half rounds -- ties).
+            const int mode = env_int("PNP_SLICE", -1);
+            c->slice_min_b = mode == 1 ? 1 : env_int("PNP_SLICE_MIN_B", 224);
+            c->slice_force = (mode == 1);
+            if (c->fused && mode != 0 && Bmax >= c->slice_min_b) {
                 c->slice = slice256_create(Bmax, &fe);
                 if (!c->slice) { fused256_destroy(c->fused); c->fused = nullptr; }
             }
@@ -270,12 +280,21 @@ static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_i
     return PNP_OK;
 }
 
+// one workgroup per slice and compute unit: the last round of a batch should be at least 80 % full
+static bool slice_pays(pnp_ctx* c) {
+    if (c->slice_force) return true;
+    if (c->B < c->slice_min_b) return false;
+    const int cus = slice256_cus(c->slice);
+    const int rounds = (c->B + cus - 1) / cus;
+    return 5 * c->B >= 4 * rounds * cus;
+}
+
 static int prepare_fused(pnp_ctx* c) {
     c->slice_ready = false;
     if (c->fused) {
         HIPCHK(fused256_prepare(c->fused, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
         c->fused_ready = true;
-        if (c->slice) {
+        if (c->slice && slice_pays(c)) {
             HIPCHK(slice256_prepare(c->slice, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
             c->slice_ready = true;
         }

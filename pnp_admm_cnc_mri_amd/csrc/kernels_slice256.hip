@@ -29,6 +29,16 @@
 #include "slice_layout.h"
 #include "fused_pointwise.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#ifndef SLICE_DFT16
+#define SLICE_DFT16 dft16      // dft16: free interleaving of the butterflies (measured +14 % with 256 VGPRs); dft16_lp: kept apart
+#endif
+#ifndef SLICE_PF
+#define SLICE_PF 2          // row pairs of z / w fetched ahead of a set's transforms (experiment knob)
+#endif
 
 namespace pnp {
 
@@ -45,10 +55,13 @@ struct SliceArgs {
     int B, iters;
     float scale, c;
     ProxCoef prox;
+    int stagger_ticks;        // start delay step (wall_clock64 ticks, 100 MHz): workgroup b waits (b & 3) steps
+    long long* prof;          // optional phase clock dump (PNP_SLICE_PROF): [block][1 + 4 per iteration] of wall_clock64()
 };
 
 constexpr int WREG = 4 * 272;                 // complex elements of a wave's private LDS region: 4 transform groups x (16 runs of 17)
-constexpr int SL_LDS = 16 * WREG + 256;       // 16 wave regions (the transposition buffer aliases them) + W256 table
+constexpr int SL_LDS = SL_BUF + 256;           // transposition buffer (the 8 wave regions alias its start) + W256 table
+static_assert(SL_WAVES * WREG <= SL_BUF, "wave regions must fit in the buffer they alias");
 
 // wave-synchronous ordering of LDS traffic: a wave's LDS instructions execute in order, so no
 // s_barrier is needed between lanes of one wave -- only the compiler has to keep the order
@@ -56,7 +69,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef SLICE_SYNC_SCHED_BARRIER             // experiment knob: also stop the scheduler here (measured slower)
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // Hides a lane-dependent value from loop-invariant code motion: without it hipcc precomputes the
@@ -79,6 +94,9 @@ __device__ __forceinline__ bufrsrc make_rsrc(const void* base, unsigned bytes) {
 // z / w that THIS workgroup stored one iteration earlier inside the same launch, and a store does not
 // refresh a line the L1 still holds from the earlier load (seen on the GPU as a few stale 64-byte sectors).
 __device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]) {
+#ifdef SLICE_ABLATE_ROWMEM          // timing experiment only (results are wrong)
+    v[0] = v[1] = v[2] = v[3] = 0.25f; return;
+#endif
     const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
     v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
 }
@@ -90,6 +108,10 @@ __device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]
 __device__ __forceinline__ void st4(bufrsrc r, int voff, int soff, const float (&v)[4]) {
     u32x4 q;
     q.x = __float_as_uint(v[0]); q.y = __float_as_uint(v[1]); q.z = __float_as_uint(v[2]); q.w = __float_as_uint(v[3]);
+#ifdef SLICE_ABLATE_ROWSTORE        // timing experiment only (results are wrong)
+    if (q.x == 0x7fc12345u) __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, 0);
+    return;
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, 0);
 }
 __device__ __forceinline__ c32 ldc(bufrsrc r, int voff, int soff) {
@@ -148,7 +170,7 @@ __device__ __forceinline__ void dft16_lp(c32 (&a)[16]) {
 // 16-lane FFT-256 on a[16] (lane t holds index t + 16 j), exchange through the group's region
 template <bool INV>
 __device__ __forceinline__ void group_fft256(c32 (&a)[16], const c32* twl, c32* region, int t) {
-    dft16_lp<INV>(a);
+    SLICE_DFT16<INV>(a);
     // twl is stored per lane: twl[16 t + k] = W256^(t k): one address register + immediate offsets,
     // fetched after the butterflies (not piled up in registers before them)
     mem_fence_compiler();
@@ -164,18 +186,40 @@ __device__ __forceinline__ void group_fft256(c32 (&a)[16], const c32* twl, c32* 
 #pragma unroll
     for (int n = 0; n < 16; ++n) a[n] = region[t * 17 + n];
     wave_sync();
-    dft16_lp<INV>(a);
+    SLICE_DFT16<INV>(a);
 }
 
 // ------------------------------------------------------------------------------------------
-// rows: one register set = the share of 4 row pairs (8 image rows) this wave owns
+// rows: one register set = the share of 4 row pairs (8 image rows) this wave owns.
+// The z / w values of a set are FETCHED AHEAD (issued before the previous set's forward transform,
+// consumed after this set's inverse transform), so HBM latency hides behind the wave's own FFT work.
 // ------------------------------------------------------------------------------------------
+struct RowLoads {              // [row pair of the set][4 consecutive pixels]; a = image row 2rr, b = row 2rr + 1
+    float za[4][4], wa[4][4], zb[4][4], wb[4][4];
+};
+
+template <int PROX, bool HAS_INV, int I0, int I1>
+__device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L, int set, int wv, int lane) {
+    const int voff = 16 * lane;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const int soff = (2 * (32 * set + 4 * wv + i)) * 1024;            // wave-uniform byte offset of image row 2rr
+        if (PROX == 3) {                                                   // single-state ADMM_L1: only the w buffer (it carries u)
+            ld4(b.w, voff, soff, L.wa[i]);
+            ld4(b.w, voff, soff + 1024, L.wb[i]);
+        } else if (PROX != 0 || !HAS_INV) {
+            ld4(b.z, voff, soff, L.za[i]); ld4(b.w, voff, soff, L.wa[i]);
+            ld4(b.z, voff, soff + 1024, L.zb[i]); ld4(b.w, voff, soff + 1024, L.wb[i]);
+        }
+    }
+}
+
 // Pointwise phase of ONE row pair for 4 consecutive pixels per lane; the arithmetic of pointwise4
 // (fused_pointwise.h) operation for operation, with re = image row 2rr and im = row 2rr + 1 of the same slice.
 // cell: the 4 complex LDS values (x in, v out); voff = 16 lane; soff = byte offset of row 2rr in the slice.
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32* cell,
-                                                  int voff, int soff) {
+                                                  int voff, int soff, float (&za)[4], float (&wa)[4], float (&zb)[4], float (&wb)[4]) {
     const int soffb = soff + 1024;
     float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
     if (HAS_INV) {
@@ -186,10 +230,7 @@ __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const Prox
         xa[2] = fabsf(c23.x) * scale; xb[2] = fabsf(c23.y) * scale;
         xa[3] = fabsf(c23.z) * scale; xb[3] = fabsf(c23.w) * scale;
     }
-    float za[4] = {0, 0, 0, 0}, wa[4] = {0, 0, 0, 0}, zb[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
     if (PROX == 3) {                                   // ADMM_L1 single-state form: the w buffer carries u = x + w_old
-        ld4(b.w, voff, soff, wa);
-        ld4(b.w, voff, soffb, wb);
         float ua[4], ub[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -210,10 +251,6 @@ __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const Prox
             st4(b.z, voff, soffb, zb); st4(b.w, voff, soffb, wb);
         }
     }
-    if ((PROX != 0 && PROX != 3) || !HAS_INV) {
-        ld4(b.z, voff, soff, za); ld4(b.w, voff, soff, wa);
-        ld4(b.z, voff, soffb, zb); ld4(b.w, voff, soffb, wb);
-    }
     if (PROX == 1 || PROX == 2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -233,30 +270,45 @@ __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const Prox
     }
 }
 
+// all four register sets of a wave; loads of set s + 1 are in flight during the transforms around them
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__device__ __forceinline__ void row_set(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32 (&a)[16], int set,
-                                        c32* wreg, const c32* twl, int wv, int lane) {
+__device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32 (&F)[SL_SETS][16],
+                                          c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * 272;
-    if (HAS_INV) {
-        group_fft256<true>(a, twl, region, t);
+    // PF row pairs of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
+    constexpr int PF = (PROX == 3) ? 4 : SLICE_PF;
+    RowLoads L;
+    issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, 0, wv, lane);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];           // natural order: element n of row pair g
-        wave_sync();
-    }
-    // the wave's 4 row pairs: 4 consecutive pixels per lane, one full 1-KiB image row per access
+    for (int set = 0; set < SL_SETS; ++set) {
+        c32 (&a)[16] = F[set];
+        if (HAS_INV) {
+#ifndef SLICE_ABLATE_ROWFFT
+            group_fft256<true>(a, twl, region, t);
+#endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int soff = (2 * (64 * set + 4 * wv + i)) * 1024;           // wave-uniform: byte offset of image row 2rr
-        pointwise_rowpair<HAS_INV, PROX, HAS_FWD, WRITE_X>(b, pc, scale, u_first, wreg + i * 272 + 4 * lane, 16 * lane, soff);
-        if (i == 1) mem_fence_compiler();            // two row pairs' loads in flight at a time (8 x 16 B per lane)
-    }
-    if (HAS_FWD) {
-        wave_sync();
+            for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];       // natural order: element n of row pair g
+            wave_sync();
+        }
+        issue_row_loads<PROX, HAS_INV, PF, 4>(b, L, set, wv, lane);
+        // the wave's 4 row pairs: 4 consecutive pixels per lane, one full 1-KiB image row per access
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = region[t + 16 * j];
-        wave_sync();
-        group_fft256<false>(a, twl, region, t);
+        for (int i = 0; i < 4; ++i) {
+            const int soff = (2 * (32 * set + 4 * wv + i)) * 1024;
+            pointwise_rowpair<HAS_INV, PROX, HAS_FWD, WRITE_X>(b, pc, scale, u_first, wreg + i * 272 + 4 * lane, 16 * lane, soff,
+                                                               L.za[i], L.wa[i], L.zb[i], L.wb[i]);
+        }
+        if (set + 1 < SL_SETS) issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, set + 1, wv, lane);
+        if (HAS_FWD) {
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = region[t + 16 * j];
+            wave_sync();
+#ifndef SLICE_ABLATE_ROWFFT
+            group_fft256<false>(a, twl, region, t);
+#endif
+        }
     }
 }
 
@@ -276,114 +328,137 @@ __device__ __forceinline__ void row_set(const SliceBufs& b, const ProxCoef& pc, 
     X(8, 12, ((t) ? SL_M + 64 - (t) : SL_M))                                                      \
     X(9, 9, SL_M + 48 - (t)) X(10, 10, SL_M + 32 - (t)) X(11, 11, SL_M + 16 - (t))
 
+// row-form registers of one set -> buffer row `rp`
 template <int P>
-__device__ __forceinline__ void t1_pass(const c32 (&F0)[16], const c32 (&F1)[16], c32 (&G)[16], c32* buf, int wv, int lane) {
-    const int g = lane >> 4, t = lane & 15;
-    {
-        c32* r0 = buf + (4 * wv + g) * SL_P;              // row pair of set 0; set 1 is 64 row pairs further
-        c32* r1 = r0 + 64 * SL_P;
-#define SL_T1_STORE(ja, jb, slot) { r0[slot] = t ? F0[ja] : F0[jb]; r1[slot] = t ? F1[ja] : F1[jb]; }
-        if (P == 0) { SL_PASS0_REGS(SL_T1_STORE, t) } else { SL_PASS1_REGS(SL_T1_STORE, t) }
+__device__ __forceinline__ void t_store_rows(const c32 (&F)[16], c32* rp, int t) {
+#define SL_T1_STORE(ja, jb, slot) { rp[slot] = t ? F[ja] : F[jb]; }
+    if (P == 0) { SL_PASS0_REGS(SL_T1_STORE, t) } else { SL_PASS1_REGS(SL_T1_STORE, t) }
 #undef SL_T1_STORE
+}
+// buffer row `rp` -> row-form registers of one set (lane 0 of a group is fixed up after pass 1)
+template <int P>
+__device__ __forceinline__ void t_load_rows(c32 (&F)[16], const c32* rp, int t) {
+#define SL_T2_LOAD(ja, jb, slot) { F[ja] = rp[slot]; }
+    if (P == 0) { SL_PASS0_REGS(SL_T2_LOAD, t) } else { SL_PASS1_REGS(SL_T2_LOAD, t) }
+#undef SL_T2_LOAD
+    if (P == 1) {         // lane 0 received k = 128 in register 12 (pass 0) and k = 192 in register 8 (pass 1): swap them
+        const c32 a0 = F[8];
+        F[8] = t ? a0 : F[12];
+        F[12] = t ? F[12] : a0;
     }
+}
+
+template <int P>
+__device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL_SETS][16], c32* buf, int wv, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+#pragma unroll
+    for (int set = 0; set < SL_SETS; ++set) t_store_rows<P>(F[set], buf + (32 * set + 4 * wv + g) * SL_P, t);
     __syncthreads();
-    {
-        const int cc = 4 * wv + g, odd = t & 1;
-        const bool packed = (P == 0 && cc == 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                       // the two column-form sets of this pass: 2P and 2P + 1
+        const int cc = 32 * h + 4 * wv + g, odd = t & 1;
+        const bool packed = (P == 0 && h == 0 && cc == 0);
         const c32* col = buf + (t >> 1) * SL_P + cc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const c32 d = col[8 * j * SL_P], m = col[8 * j * SL_P + SL_M];
             const c32 va = packed ? mk<float>(d.x, m.x) : unpack_a(d, m);
             const c32 vb = packed ? mk<float>(d.y, m.y) : unpack_b(d, m);
-            G[j] = odd ? vb : va;
-            pin(G[j]);                            // unpack as the values arrive: raw pairs must not pile up across the barrier
-            if ((j & 3) == 3) sched_fence();
+            G[2 * P + h][j] = odd ? vb : va;
+            pin(G[2 * P + h][j]);                       // unpack as the values arrive: raw pairs must not pile up across the barrier
         }
     }
     __syncthreads();
 }
 
 template <int P>
-__device__ __forceinline__ void t2_pass(const c32 (&G)[16], c32 (&F0)[16], c32 (&F1)[16], c32* buf, int wv, int lane) {
+__device__ __forceinline__ void t2_pass(const c32 (&G)[SL_SETS][16], c32 (&F)[SL_SETS][16], c32* buf, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
-    {
-        const int cc = 4 * wv + g, odd = t & 1;
-        const bool packed = (P == 0 && cc == 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cc = 32 * h + 4 * wv + g, odd = t & 1;
+        const bool packed = (P == 0 && h == 0 && cc == 0);
         c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const c32 other = dpp_lane_xor1(G[j]);
-            const c32 ue = odd ? other : G[j], uo = odd ? G[j] : other;
+            const c32 own = G[2 * P + h][j];
+            const c32 other = dpp_lane_xor1(own);
+            const c32 ue = odd ? other : own, uo = odd ? own : other;
             const c32 dp = packed ? mk<float>(ue.x, uo.x) : repack_p(ue, uo);
             const c32 dq = packed ? mk<float>(ue.y, uo.y) : repack_q(ue, uo);
             col[8 * j * SL_P] = odd ? dq : dp;
-            if ((j & 3) == 3) sched_fence();
         }
     }
     __syncthreads();
-    {
-        const c32* r0 = buf + (4 * wv + g) * SL_P;
-        const c32* r1 = r0 + 64 * SL_P;
-#define SL_T2_LOAD(ja, jb, slot) { F0[ja] = r0[slot]; F1[ja] = r1[slot]; }      /* lane 0 of a group: fixed up after pass 1 */
-        if (P == 0) { SL_PASS0_REGS(SL_T2_LOAD, t) } else { SL_PASS1_REGS(SL_T2_LOAD, t) }
-        if (P == 1) {     // lane 0 received k = 128 in register 12 (pass 0) and k = 192 in register 8 (pass 1): swap them
-            const c32 a0 = F0[8], a1 = F1[8];
-            F0[8] = t ? a0 : F0[12]; F0[12] = t ? F0[12] : a0;
-            F1[8] = t ? a1 : F1[12]; F1[12] = t ? F1[12] : a1;
-        }
-#undef SL_T2_LOAD
-    }
+#pragma unroll
+    for (int set = 0; set < SL_SETS; ++set) t_load_rows<P>(F[set], buf + (32 * set + 4 * wv + g) * SL_P, t);
     __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
-// columns: one register set = the share of 4 columns this wave owns
+// columns: one register set = the share of 4 columns this wave owns; operands fetched one set ahead
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void col_set(const SliceBufs& b, float cdc, c32 (&a)[16], int set, c32* wreg, const c32* twl, int wv, int lane) {
+struct ColLoads {
+    c32 yh[16];
+    uint32_t code;
+};
+__device__ __forceinline__ void issue_col_loads(const SliceBufs& b, ColLoads& Y, int set, int wv, int lane) {
+    const int ybase = ((set * 16) * 8 + wv) * 64 * 8;              // yh3_index(.., set, j = 0, wv, lane = 0) in bytes; + j * 4096
+    Y.code = __builtin_amdgcn_raw_buffer_load_b32(b.mh, 4 * lane, (set * 8 + wv) * 64 * 4, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Y.yh[j] = ldc(b.yh, 8 * lane, ybase + j * 4096);
+}
+
+__device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G)[SL_SETS][16], c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * 272;
-    group_fft256<false>(a, twl, region, t);                       // a[j] = spectrum at k1 = t + 16 j, k2 = c
-    mem_fence_compiler();                                         // operand loads start here, not before the transform
-    // table rows are in thread order: wave-uniform byte offset + 8 (4) bytes per lane
-    const int ybase = ((set * 16) * 16 + wv) * 64 * 8;            // yh3_index(.., set, j = 0, wv, lane = 0) in bytes; + j * 8192
-    const uint32_t code = __builtin_amdgcn_raw_buffer_load_b32(b.mh, 4 * lane, (set * 16 + wv) * 64 * 4, 0);
     const float ch = 0.5f * cdc;
-    if (set == 0 && wv == 0 && g == 0) {
-        // packed column: a = A + i B, A / B = spectra of the real columns k2 = 0 / 128; split with the mirror k1 -> -k1
+    ColLoads Y;
+    issue_col_loads(b, Y, 0, wv, lane);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];
-        wave_sync();
-        const uint32_t code_b = __builtin_amdgcn_raw_buffer_load_b32(b.ms, 4 * t, 0, 0);
+    for (int set = 0; set < SL_SETS; ++set) {
+        c32 (&a)[16] = G[set];
+        group_fft256<false>(a, twl, region, t);                   // a[j] = spectrum at k1 = t + 16 j, k2 = c
+        if (set == 0 && wv == 0 && g == 0) {
+            // packed column: a = A + i B, A / B = spectra of the real columns k2 = 0 / 128; split with the mirror k1 -> -k1
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const c32 gm = region[(256 - (t + 16 * j)) & 255];
-            const c32 A = blend_one(unpack_a(a[j], gm), ldc(b.yh, 8 * lane, ybase + j * 8192), (int)((code >> (2 * j)) & 3u), cdc, ch);
-            const c32 Bv = blend_one(unpack_b(a[j], gm), ldc(b.ys, 8 * t, 128 * j), (int)((code_b >> (2 * j)) & 3u), cdc, ch);
-            a[j] = repack_p(A, Bv);
+            for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];
+            wave_sync();
+            const uint32_t code_b = __builtin_amdgcn_raw_buffer_load_b32(b.ms, 4 * t, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const c32 gm = region[(256 - (t + 16 * j)) & 255];
+                const c32 A = blend_one(unpack_a(a[j], gm), Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, ch);
+                const c32 Bv = blend_one(unpack_b(a[j], gm), ldc(b.ys, 8 * t, 128 * j), (int)((code_b >> (2 * j)) & 3u), cdc, ch);
+                a[j] = repack_p(A, Bv);
+            }
+            wave_sync();
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = blend_one(a[j], Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, ch);
         }
-        wave_sync();
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = blend_one(a[j], ldc(b.yh, 8 * lane, ybase + j * 8192), (int)((code >> (2 * j)) & 3u), cdc, ch);
-        mem_fence_compiler();                                     // 8 operand loads (16 registers) in flight at a time
-#pragma unroll
-        for (int j = 8; j < 16; ++j) a[j] = blend_one(a[j], ldc(b.yh, 8 * lane, ybase + j * 8192), (int)((code >> (2 * j)) & 3u), cdc, ch);
+        if (set + 1 < SL_SETS) issue_col_loads(b, Y, set + 1, wv, lane);
+        group_fft256<true>(a, twl, region, t);                    // column c of the blended field, unnormalised
     }
-    group_fft256<true>(a, twl, region, t);                        // column c of the blended field, unnormalised
 }
 
 // ------------------------------------------------------------------------------------------
 // PROX: 1 L1 (z and w), 2 CNC, 3 L1 single-state (see fused_pointwise.h)
 // ------------------------------------------------------------------------------------------
 template <int PROX>
-__global__ __launch_bounds__(1024) void k_slice(SliceArgs p) {
+__global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     __shared__ __attribute__((aligned(16))) c32 lds[SL_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index as a scalar: bases below stay in SGPRs
-    c32* twl = lds + 16 * WREG;
+    c32* twl = lds + SL_BUF;
     if (tid < 256) twl[tid] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k)
     c32* wreg = lds + wv * WREG;
+    if (p.stagger_ticks > 0) {
+        // Equal workgroups started together run their HBM-heavy row phases together, chip-wide.  A one-time
+        // start offset of a quarter iteration per residue class spreads the phases so that HBM always has takers.
+        const long long t0 = wall_clock64(), wait = (long long)(blockIdx.x & 3) * p.stagger_ticks;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     __syncthreads();
     for (int slice = blockIdx.x; slice < p.B; slice += gridDim.x) {
         const size_t so = (size_t)slice * 65536;
@@ -391,27 +466,27 @@ __global__ __launch_bounds__(1024) void k_slice(SliceArgs p) {
         b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + so, 65536 * 4);
         b.yh = make_rsrc(p.Yh + (size_t)slice * YH3_SLICE, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
         b.ys = make_rsrc(p.Ys + (size_t)slice * 256, 256 * 8); b.ms = make_rsrc(p.Ms + (size_t)slice * 16, 16 * 4);
-        c32 F0[16], F1[16];
-        row_set<false, 0, true, false>(b, p.prox, p.scale, 1, F0, 0, wreg, twl, wv, opaque(lane));
-        row_set<false, 0, true, false>(b, p.prox, p.scale, 1, F1, 1, wreg, twl, wv, opaque(lane));
+        c32 F[SL_SETS][16];
+        long long* prof = (p.prof && tid == 0 && slice == blockIdx.x) ? p.prof + (size_t)blockIdx.x * (2 + 4 * p.iters) : nullptr;
+        if (prof) *prof++ = wall_clock64();
+        row_phase<false, 0, true, false>(b, p.prox, p.scale, 1, F, wreg, twl, wv, opaque(lane));
+        if (prof) *prof++ = wall_clock64();
         for (int it = 0; it < p.iters; ++it) {
-            c32 G0[16], G1[16];
+            c32 G[SL_SETS][16];
             __syncthreads();                      // every wave is done with its private region: the buffer aliases them
-            t1_pass<0>(F0, F1, G0, lds, wv, opaque(lane));
-            t1_pass<1>(F0, F1, G1, lds, wv, opaque(lane));
-            col_set(b, p.c, G0, 0, wreg, twl, wv, opaque(lane));
-            col_set(b, p.c, G1, 1, wreg, twl, wv, opaque(lane));
+            t1_pass<0>(F, G, lds, wv, opaque(lane));
+            t1_pass<1>(F, G, lds, wv, opaque(lane));
+            if (prof) *prof++ = wall_clock64();
+            col_phase(b, p.c, G, wreg, twl, wv, opaque(lane));
             __syncthreads();
-            t2_pass<0>(G0, F0, F1, lds, wv, opaque(lane));
-            t2_pass<1>(G1, F0, F1, lds, wv, opaque(lane));
+            if (prof) *prof++ = wall_clock64();
+            t2_pass<0>(G, F, lds, wv, opaque(lane));
+            t2_pass<1>(G, F, lds, wv, opaque(lane));
+            if (prof) *prof++ = wall_clock64();
             const int u_first = (it == 0);
-            if (it + 1 < p.iters) {
-                row_set<true, PROX, true, false>(b, p.prox, p.scale, u_first, F0, 0, wreg, twl, wv, opaque(lane));
-                row_set<true, PROX, true, false>(b, p.prox, p.scale, u_first, F1, 1, wreg, twl, wv, opaque(lane));
-            } else {
-                row_set<true, PROX, false, true>(b, p.prox, p.scale, u_first, F0, 0, wreg, twl, wv, opaque(lane));
-                row_set<true, PROX, false, true>(b, p.prox, p.scale, u_first, F1, 1, wreg, twl, wv, opaque(lane));
-            }
+            if (it + 1 < p.iters) row_phase<true, PROX, true, false>(b, p.prox, p.scale, u_first, F, wreg, twl, wv, opaque(lane));
+            else                  row_phase<true, PROX, false, true>(b, p.prox, p.scale, u_first, F, wreg, twl, wv, opaque(lane));
+            if (prof) *prof++ = wall_clock64();
         }
         __syncthreads();
     }
@@ -430,7 +505,7 @@ __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* m
     int code;
     hermitian_entry_t<float>(y + (size_t)slice * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh, code);
     codes[k1] = code;
-    const int c = k2 & 127, set = c >> 6, wv = (c & 63) >> 2, lane = 16 * (c & 3) + t;
+    const int c = k2 & 127, set = c >> 5, wv = (c & 31) >> 2, lane = 16 * (c & 3) + t;
     if (k2 < 128) Yh[yh3_index(slice, set, j, wv, lane)] = yh;
     else          Ys[(size_t)slice * 256 + k1] = yh;
     __syncthreads();
@@ -453,6 +528,8 @@ struct Slice256 {
     c32* Ys = nullptr;
     uint32_t* Ms = nullptr;
 };
+
+int slice256_cus(const Slice256* f) { return f && f->cus > 0 ? f->cus : 256; }
 
 void slice256_destroy(Slice256* f) {
     if (!f) return;
@@ -508,11 +585,36 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     a.z = z; a.w = w; a.x = x; a.Yh = f->Yh; a.Mh = f->Mh; a.Ys = f->Ys; a.Ms = f->Ms;
     a.B = B; a.iters = iters; a.scale = 1.0f / 65536.0f; a.c = dc_c;
     a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
-    // one workgroup per slice; a workgroup fills a compute unit (1024 threads x 128 VGPRs, 138 KiB of LDS)
+    a.prof = nullptr;
+    {
+        const char* e = getenv("PNP_SLICE_STAGGER_US");          // default: a quarter of a slice-iteration (~20 us)
+        const double us = e ? atof(e) : 20.0;
+        a.stagger_ticks = (iters >= 4) ? (int)(us * 100.0) : 0;  // not worth it for very short runs
+    }
+    long long* d_prof = nullptr;
+    const char* prof_path = getenv("PNP_SLICE_PROF");          // debugging aid: dump per-phase clocks of each workgroup's first slice
+    const size_t prof_n = (size_t)B * (2 + 4 * (size_t)iters);
+    if (prof_path && hipMalloc((void**)&d_prof, prof_n * sizeof(long long)) == hipSuccess) {
+        (void)hipMemsetAsync(d_prof, 0, prof_n * sizeof(long long), s);
+        a.prof = d_prof;
+    }
+    // one workgroup per slice; a workgroup fills a compute unit (512 threads x 256 VGPRs, 134 KiB of LDS)
     const dim3 grid(B);
-    if (cnc)                    hipLaunchKernelGGL(k_slice<2>, grid, dim3(1024), 0, s, a);
-    else if (sch.l1_two_state)  hipLaunchKernelGGL(k_slice<1>, grid, dim3(1024), 0, s, a);
-    else                        hipLaunchKernelGGL(k_slice<3>, grid, dim3(1024), 0, s, a);
+    if (cnc)                    hipLaunchKernelGGL(k_slice<2>, grid, dim3(512), 0, s, a);
+    else if (sch.l1_two_state)  hipLaunchKernelGGL(k_slice<1>, grid, dim3(512), 0, s, a);
+    else                        hipLaunchKernelGGL(k_slice<3>, grid, dim3(512), 0, s, a);
+    if (d_prof) {
+        std::vector<long long> h(prof_n);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), d_prof, prof_n * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(d_prof);
+        if (FILE* f = fopen(prof_path, "wb")) {
+            const int hdr[2] = {B, iters};
+            fwrite(hdr, sizeof(int), 2, f);
+            fwrite(h.data(), sizeof(long long), prof_n, f);
+            fclose(f);
+        }
+    }
     return hipGetLastError();
 }
 

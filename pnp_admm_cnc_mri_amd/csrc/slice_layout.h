@@ -1,20 +1,21 @@
 // Index maps of the slice-resident 256x256 kernel (kernels_slice256.hip), shared with the g++ host
 // emulation (tests/host/slice_resident_emulation.cpp).
 //
-// One 1024-thread workgroup keeps ONE real slice on a compute unit for a whole ADMM run: the
-// 65536 values live in the register file (64 VGPRs per thread) as 128 complex rows or 128 complex
-// columns of 256, and only z, w (and the Hermitian measurement table) travel to HBM.
+// One 512-thread workgroup (8 waves, 2 per SIMD, 256 VGPRs each) keeps ONE real slice on a compute
+// unit for a whole ADMM run: the 65536 values live in the register file (128 VGPRs per thread, four
+// "register sets" of 16 complex values) as 128 complex rows or 128 complex columns of 256, and only
+// z, w (and the Hermitian measurement table) travel to HBM.
 //
 //   row form   : row pair r = 0..127 carries c_r[n] = v[2r][n] + i v[2r+1][n]; its transform C_r[k]
 //                is held by the 16 lanes of a group as C_r[t + 16 j] (lane t, register j).
-//                thread (wave wv, lane l), register set s:  r = 64 s + 4 wv + (l >> 4),  t = l & 15
+//                thread (wave wv, lane l), register set s:  r = 32 s + 4 wv + (l >> 4),  t = l & 15
 //   column form: column c = 0..127; c >= 1 is k-space column k2 = c of the real slice's row
 //                transforms V_rho[k2] (rho = 0..255), c = 0 packs the two real columns k2 = 0 and
 //                k2 = 128 as V_rho[0] + i V_rho[128].  Same thread shape:
-//                c = 64 s + 4 wv + (l >> 4),  lane t holds rho (or k1) = t + 16 j
+//                c = 32 s + 4 wv + (l >> 4),  lane t holds rho (or k1) = t + 16 j
 //
 // Row form <-> column form goes through LDS in two passes (the buffer holds half the field):
-//   pass p moves the columns c = 64 p .. 64 p + 63.  A row pair needs, per column c, C_r[c] and its
+//   pass p moves the columns c = 64 p .. 64 p + 63 (register sets 2p and 2p + 1 of the column form).  A row pair needs, per column c, C_r[c] and its
 //   mirror C_r[256 - c] (for c = 0: C_r[0] and C_r[128]) because
 //     V_2r[k2] = (C_r[k2] + conj C_r[-k2]) / 2,   V_2r+1[k2] = (C_r[k2] - conj C_r[-k2]) / (2i)
 //   buffer element (r, slot): slot = c - 64 p for the direct value, SL_M + c - 64 p for the mirror.
@@ -42,18 +43,19 @@ PNP_HD int sl_slot(int k) {
     return SL_M + 192 - k;                     // pass 1, mirror of c = 256 - k = 64..127  (k = 129..192)
 }
 // thread shape shared by both forms
-PNP_HD int sl_unit(int set, int wv, int lane) { return 64 * set + 4 * wv + (lane >> 4); }     // r or c
+constexpr int SL_WAVES = 8, SL_SETS = 4;
+PNP_HD int sl_unit(int set, int wv, int lane) { return 32 * set + 4 * wv + (lane >> 4); }     // r or c
 
 // per-slice operand tables in column-form thread order
-//   Yh3 : [slice][set 2][j 16][wave 16][lane 64] complex   Yh at (k1 = t + 16 j, k2 = c); for c = 0: k2 = 0
-//   Mh3 : [slice][set 2][wave 16][lane 64] u32, 2 bits per j = 2 Mh
+//   Yh3 : [slice][set 4][j 16][wave 8][lane 64] complex   Yh at (k1 = t + 16 j, k2 = c); for c = 0: k2 = 0
+//   Mh3 : [slice][set 4][wave 8][lane 64] u32, 2 bits per j = 2 Mh
 //   Ys3 : [slice][256] complex, Ms3 : [slice][16] u32 -- the same for k2 = 128 (second half of c = 0), lane t, bits j
-constexpr size_t YH3_SLICE = 2 * 16 * 16 * 64;
-constexpr size_t MH3_SLICE = 2 * 16 * 64;
+constexpr size_t YH3_SLICE = 4 * 16 * 8 * 64;
+constexpr size_t MH3_SLICE = 4 * 8 * 64;
 PNP_HD size_t yh3_index(int slice, int set, int j, int wv, int lane) {
-    return (size_t)slice * YH3_SLICE + ((((size_t)set * 16 + j) * 16 + wv) * 64 + lane);
+    return (size_t)slice * YH3_SLICE + ((((size_t)set * 16 + j) * 8 + wv) * 64 + lane);
 }
-PNP_HD size_t mh3_index(int slice, int set, int wv, int lane) { return (size_t)slice * MH3_SLICE + (((size_t)set * 16 + wv) * 64 + lane); }
+PNP_HD size_t mh3_index(int slice, int set, int wv, int lane) { return (size_t)slice * MH3_SLICE + (((size_t)set * 8 + wv) * 64 + lane); }
 
 // the packed column c = 0 after its transform: G[k1] = A[k1] + i B[k1] with A, B the transforms of the
 // REAL columns k2 = 0 and k2 = 128:  A = unpack_a(G[k1], G[-k1]),  B = unpack_b(G[k1], G[-k1]),

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (gpurun_out/prof_kt, prof_fetch, prof_write) into the small tracked
-files under profiles/: kernel stats of the pnp:: kernels and per-launch HBM traffic.
+"""Condense rocprofv3 output of profiles/collect.sh (gpurun_out/prof_<name>/{kt,fetch,write}) into the small
+tracked files under profiles/: per-kernel time and HBM traffic of the pnp:: kernels, per-iteration totals,
+and the entry of profiles/traffic.json that bench.py reports as roofline.traffic.
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B
-(MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024; the correction is
-confirmed here on kernels whose byte counts are known exactly (k_frows<first>: reads z and w only,
-2 * 131,127 KiB = 268.5 MB = 2 arrays x 512 slices x 256 KiB).
-usage: python profiles/summarize.py <round-tag>
+(MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024; the correction is confirmed on
+kernels whose byte counts are known exactly (k_frows<first>: reads z and w only, 2 * 131,127 KiB = 268.5 MB
+= 2 arrays x 512 slices x 256 KiB).
+usage: python profiles/summarize.py <round-tag> <name> [<name> ...]
 """
 import collections
 import csv
@@ -17,76 +18,93 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'gpurun_out')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-update_traffic = '--no-traffic' not in sys.argv
+LOOP = ('k_frows', 'k_fcols', 'k_fmixed', 'k5_rows', 'k5_cols', 'k_slice', 'k_rows', 'k_cols')
 
 
 def short(name):
-    name = name.replace('pnp::', '').replace('void ', '')
-    return name.split('(')[0]
+    return name.replace('pnp::', '').replace('void ', '').split('(')[0]
 
 
-stats = []
-f = max(glob.glob(os.path.join(G, 'prof_kt', '*', '*_kernel_stats.csv')), key=os.path.getmtime)
-for r in csv.DictReader(open(f)):
-    if 'pnp::' in r['Name']:
-        stats.append({'kernel': short(r['Name']), 'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
-                      'min_us': float(r['MinNs']) / 1e3, 'max_us': float(r['MaxNs']) / 1e3,
-                      'total_ms': float(r['TotalDurationNs']) / 1e6, 'pct': float(r['Percentage'])})
-pmc = collections.defaultdict(dict)
-for name, ctr in (('prof_fetch', 'FETCH_SIZE'), ('prof_write', 'WRITE_SIZE')):
-    fs = glob.glob(os.path.join(G, name, '*', '*_counter_collection.csv'))
-    if not fs:
-        continue
-    acc = collections.defaultdict(list)
-    meta = {}
-    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
-        if 'pnp::' in r['Kernel_Name'] and r['Counter_Name'] == ctr:
-            acc[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
-            meta[short(r['Kernel_Name'])] = (int(r['VGPR_Count']), int(r['LDS_Block_Size']), int(r['Grid_Size']))
-    for k, v in acc.items():
-        pmc[k][ctr + '_KiB_avg'] = sum(v) / len(v)
-        pmc[k]['launches_' + ctr] = len(v)
-        pmc[k]['vgpr'], pmc[k]['lds_bytes'], pmc[k]['grid_threads'] = meta[k]
-for k, d in pmc.items():
-    rd = 2.0 * d.get('FETCH_SIZE_KiB_avg', 0) * 1024
-    wr = d.get('WRITE_SIZE_KiB_avg', 0) * 1024
-    d['read_bytes_corrected'] = rd
-    d['write_bytes'] = wr
-    d['hbm_bytes_per_launch'] = rd + wr
-bench = None
-for line in open(os.path.join(G, 'prof_kt.log')):
-    if line.startswith('{"metric"'):
-        bench = json.loads(line)
-out = {'tag': tag, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline '
-                              '(+ separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with --steps 20 --warmup 2)',
-       'kernel_stats': stats, 'pmc': pmc, 'bench_line_under_profiler': bench}
-iter_kernels = [s for s in stats if s['calls'] >= 50]
-steps = (bench or {}).get('steps', 100) + (bench or {}).get('warmup', 10)
-out['per_iteration'] = {
-    'kernels': [s['kernel'] for s in iter_kernels],
-    # launches of each loop kernel per batched iteration (2 for the sequential schedule; 4 mixed
-    # launches with two queues, which overlap pairwise)
-    'launches_per_iteration': {s['kernel']: round(s['calls'] / steps, 2) for s in iter_kernels},
-    'sum_kernel_time_us': sum(s['avg_us'] * s['calls'] / steps for s in iter_kernels),
-    'wall_us_per_iteration_hip_events': (bench or {}).get('hip_event_ms_per_step', 0) * 1e3,
-    'hbm_bytes': sum(pmc.get(s['kernel'], {}).get('hbm_bytes_per_launch', 0) * s['calls'] / steps for s in iter_kernels),
-    'algorithmic_bytes_57N': 57 * 65536 * 512,
-}
-json.dump(out, open(os.path.join(ROOT, 'profiles', 'rocprof_%s.json' % tag), 'w'), indent=1)
-with open(os.path.join(ROOT, 'profiles', 'rocprof_%s_kernel_stats.csv' % tag), 'w') as fo:
-    fo.write(open(f).read())
-print(json.dumps(out['per_iteration'], indent=1))
-for s in stats:
-    d = pmc.get(s['kernel'], {})
-    print('%-40s calls %4d avg %8.1f us  hbm %7.1f MB  -> %5.2f TB/s' % (
-        s['kernel'], s['calls'], s['avg_us'], d.get('hbm_bytes_per_launch', 0) / 1e6,
-        d.get('hbm_bytes_per_launch', 0) / (s['avg_us'] * 1e-6) / 1e12 if s['avg_us'] else 0))
-# bench.py reads this for roofline.traffic
-if not update_traffic:
-    sys.exit(0)
-tj = os.path.join(ROOT, 'profiles', 'traffic.json')
-cur = json.load(open(tj)) if os.path.exists(tj) else {}
-path = bench['config']['path'] if bench else 'fused'
-cur[path] = {'hbm_bytes_per_iteration_b512': out['per_iteration']['hbm_bytes'], 'from': 'profiles/rocprof_%s.json' % tag}
-json.dump(cur, open(tj, 'w'), indent=1)
+def newest(pattern):
+    fs = glob.glob(pattern, recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+def one(tag, name):
+    d = os.path.join(G, 'prof_' + name)
+    stats = []
+    f = newest(os.path.join(d, 'kt', '**', '*_kernel_stats.csv'))
+    for r in csv.DictReader(open(f)):
+        if 'pnp::' in r['Name']:
+            stats.append({'kernel': short(r['Name']), 'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
+                          'min_us': float(r['MinNs']) / 1e3, 'max_us': float(r['MaxNs']) / 1e3,
+                          'total_ms': float(r['TotalDurationNs']) / 1e6, 'pct': float(r['Percentage'])})
+    pmc = collections.defaultdict(dict)
+    for sub, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+        fc = newest(os.path.join(d, sub, '**', '*_counter_collection.csv'))
+        if not fc:
+            continue
+        acc, meta = collections.defaultdict(list), {}
+        for r in csv.DictReader(open(fc)):
+            if 'pnp::' in r['Kernel_Name'] and r['Counter_Name'] == ctr:
+                k = short(r['Kernel_Name'])
+                acc[k].append(float(r['Counter_Value']))
+                meta[k] = (int(r['VGPR_Count']), int(r['LDS_Block_Size']), int(r['Grid_Size']), int(r.get('Scratch_Size', 0) or 0))
+        for k, v in acc.items():
+            pmc[k][ctr + '_KiB_avg'] = sum(v) / len(v)
+            pmc[k][ctr + '_KiB_total'] = sum(v)
+            pmc[k]['launches_' + ctr] = len(v)
+            pmc[k]['vgpr'], pmc[k]['lds_bytes'], pmc[k]['grid_threads'], pmc[k]['scratch_bytes'] = meta[k]
+    for k, dd in pmc.items():
+        dd['read_bytes_corrected'] = 2.0 * dd.get('FETCH_SIZE_KiB_avg', 0) * 1024
+        dd['write_bytes'] = dd.get('WRITE_SIZE_KiB_avg', 0) * 1024
+        dd['hbm_bytes_per_launch'] = dd['read_bytes_corrected'] + dd['write_bytes']
+    bench = {}
+    for sub in ('kt', 'fetch'):
+        for line in open(os.path.join(d, sub + '.log')):
+            if line.startswith('{"metric"'):
+                bench[sub] = json.loads(line)
+    bk, bp = bench.get('kt', {}), bench.get('fetch', {})
+    it_kt = bk.get('steps', 100) + bk.get('warmup', 10)
+    it_pmc = bp.get('steps', 20) + bp.get('warmup', 2)
+    loop = [s for s in stats if any(s['kernel'].startswith(p) for p in LOOP)]
+    hbm_it = sum((2.0 * pmc[s['kernel']].get('FETCH_SIZE_KiB_total', 0) + pmc[s['kernel']].get('WRITE_SIZE_KiB_total', 0)) * 1024
+                 for s in loop if s['kernel'] in pmc) / it_pmc
+    B = bk.get('config', {}).get('slices_per_gpu', 512)
+    side = 512 if '512x512' in bk.get('config', {}).get('workload', '') else 256
+    out = {'tag': tag, 'name': name,
+           'command': 'bash profiles/collect.sh %s ...: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 '
+                      '--no-cpu-baseline <args>  (+ separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes with --steps 20 --warmup 2)' % name,
+           'bench_line_under_kernel_trace': bk, 'kernel_stats': stats, 'pmc': pmc,
+           'per_iteration': {
+               'loop_kernels': {s['kernel']: {'launches_per_iteration': round(s['calls'] / it_kt, 3), 'avg_us': s['avg_us'],
+                                              'us_per_iteration': s['avg_us'] * s['calls'] / it_kt} for s in loop},
+               'sum_kernel_time_us': sum(s['avg_us'] * s['calls'] / it_kt for s in loop),
+               'hip_event_us_per_iteration': bk.get('hip_event_ms_per_step', 0) * 1e3,
+               'hbm_bytes': hbm_it,
+               'algorithmic_bytes_57N': 57 * side * side * B}}
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'rocprof_%s_%s.json' % (tag, name)), 'w'), indent=1)
+    with open(os.path.join(ROOT, 'profiles', 'rocprof_%s_%s_kernel_stats.csv' % (tag, name)), 'w') as fo:
+        fo.write(open(f).read())
+    print('== %s: %.1f it/s under the profiler, loop kernels %.1f us/iteration, %.1f MB/iteration = %.2f x 57N' % (
+        name, bk.get('value', 0), out['per_iteration']['sum_kernel_time_us'], hbm_it / 1e6, hbm_it / (57.0 * side * side * B)))
+    for s in stats:
+        dd = pmc.get(s['kernel'], {})
+        print('  %-44s calls %4d avg %9.1f us  vgpr %3s  hbm/launch %8.1f MB -> %5.2f TB/s' % (
+            s['kernel'][:44], s['calls'], s['avg_us'], dd.get('vgpr', '-'), dd.get('hbm_bytes_per_launch', 0) / 1e6,
+            dd.get('hbm_bytes_per_launch', 0) / (s['avg_us'] * 1e-6) / 1e12 if s['avg_us'] else 0))
+    # bench.py reads this for roofline.traffic: key = path:solver:size:precision:bB
+    cfg = bk.get('config', {})
+    if cfg:
+        solver = 'l1' if 'ADMM_L1' in cfg.get('workload', '') else 'cnc'
+        key = '%s:%s:%d:%s:b%d' % (cfg.get('path'), solver, side, cfg.get('precision', 'f32'), B)
+        tj = os.path.join(ROOT, 'profiles', 'traffic.json')
+        cur = json.load(open(tj)) if os.path.exists(tj) else {}
+        cur = {k: v for k, v in cur.items() if ':' in k}
+        cur[key] = {'hbm_bytes_per_iteration': hbm_it, 'from': 'profiles/rocprof_%s_%s.json' % (tag, name)}
+        json.dump(cur, open(tj, 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    for nm in sys.argv[2:]:
+        one(sys.argv[1], nm)

@@ -15,8 +15,8 @@ typedef float R;
 typedef cxT<R> C;
 
 static C TW[256];
-static C F[16][64][2][16];        // the register file: [wave][lane][set][j]
-static C G[16][64][2][16];
+static C F[8][64][4][16];         // the register file: [wave][lane][set][j]
+static C G[8][64][4][16];
 static C LDS[SL_BUF];
 
 // 16-lane cooperative transform of the group (wave wv, lanes 16 g .. 16 g + 15), register set `set`
@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     // ---- tables of slice 0 in column-form thread order -----------------------------------------
     std::vector<C> Yh(YH3_SLICE), Ys(256);
     std::vector<uint32_t> Mh(MH3_SLICE, 0), Ms(16, 0);
-    for (int set = 0; set < 2; ++set) for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) {
+    for (int set = 0; set < SL_SETS; ++set) for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) {
         const int c = sl_unit(set, wv, lane), t = lane & 15;
         for (int j = 0; j < 16; ++j) {
             int code; C yh;
@@ -69,19 +69,19 @@ int main(int argc, char** argv) {
         Ms[t] |= (uint32_t)code << (2 * j);
     }
     // ---- rows (first): F <- row transforms of the row pairs ------------------------------------
-    for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < 2; ++set) {
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
         const int r = sl_unit(set, wv, lane), t = lane & 15;
         for (int j = 0; j < 16; ++j) {
             const int n = t + 16 * j;
             F[wv][lane][set][j] = mk<R>(z[(2 * r) * 256 + n] - w[(2 * r) * 256 + n], z[(2 * r + 1) * 256 + n] - w[(2 * r + 1) * 256 + n]);
         }
     }
-    for (int wv = 0; wv < 16; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < 2; ++set) group_fft(wv, g, set, false);
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < SL_SETS; ++set) group_fft(wv, g, set, false);
     // ---- T1: row form -> column form, two passes through the buffer ----------------------------
     for (int p = 0; p < 2; ++p) {
         for (int i = 0; i < SL_BUF; ++i) LDS[i] = mk<R>(NAN, NAN);
         int written = 0;
-        for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < 2; ++set) {
+        for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
             const int r = sl_unit(set, wv, lane), t = lane & 15;
             int mine = 0;
             for (int j = 0; j < 16; ++j) {
@@ -94,8 +94,8 @@ int main(int argc, char** argv) {
             if (mine != 8) return 7;                                              // every thread moves 8 values per set and pass
         }
         if (written != 128 * 128) return 7;
-        for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) {
-            const int set = p, c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63;
+        for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 2 * p; set < 2 * p + 2; ++set) {
+            const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63;
             for (int j = 0; j < 16; ++j) {
                 const int rho = t + 16 * j, r = rho >> 1;
                 const C d = LDS[r * SL_P + cc], m = LDS[r * SL_P + SL_M + cc];
@@ -107,10 +107,10 @@ int main(int argc, char** argv) {
             }
         }
     }
-    for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < 2; ++set) for (int j = 0; j < 16; ++j) F[wv][lane][set][j] = G[wv][lane][set][j];
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) for (int j = 0; j < 16; ++j) F[wv][lane][set][j] = G[wv][lane][set][j];
     // ---- columns: transform, blend, inverse transform ------------------------------------------
     const R ch = 0.5f * cdc;
-    for (int wv = 0; wv < 16; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < 2; ++set) {
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < SL_SETS; ++set) {
         group_fft(wv, g, set, false);
         const int c = sl_unit(set, wv, 16 * g);
         if (c == 0) {
@@ -135,8 +135,8 @@ int main(int argc, char** argv) {
     // ---- T2: column form -> row form -------------------------------------------------------------
     for (int p = 0; p < 2; ++p) {
         for (int i = 0; i < SL_BUF; ++i) LDS[i] = mk<R>(NAN, NAN);
-        for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; lane += 2) {
-            const int set = p, c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63;       // t even; lane + 1 is its partner
+        for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; lane += 2) for (int set = 2 * p; set < 2 * p + 2; ++set) {
+            const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63;                // t even; lane + 1 is its partner
             for (int j = 0; j < 16; ++j) {
                 const int r = (t + 16 * j) >> 1;
                 const C ue = F[wv][lane][set][j], uo = F[wv][lane + 1][set][j];
@@ -144,7 +144,7 @@ int main(int argc, char** argv) {
                 LDS[r * SL_P + SL_M + cc] = (c == 0) ? mk<R>(ue.y, uo.y) : repack_q(ue, uo);    // written by the odd lane
             }
         }
-        for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < 2; ++set) {
+        for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
             const int r = sl_unit(set, wv, lane), t = lane & 15;
             for (int j = 0; j < 16; ++j) {
                 const int k = t + 16 * j;
@@ -154,11 +154,11 @@ int main(int argc, char** argv) {
             }
         }
     }
-    for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < 2; ++set) for (int j = 0; j < 16; ++j) F[wv][lane][set][j] = G[wv][lane][set][j];
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) for (int j = 0; j < 16; ++j) F[wv][lane][set][j] = G[wv][lane][set][j];
     // ---- rows (last): inverse transform, x = |re|, |im| / 65536, prox --------------------------------
-    for (int wv = 0; wv < 16; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < 2; ++set) group_fft(wv, g, set, true);
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < SL_SETS; ++set) group_fft(wv, g, set, true);
     const R scale = 1.0f / 65536.0f;
-    for (int wv = 0; wv < 16; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < 2; ++set) {
+    for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
         const int r = sl_unit(set, wv, lane), t = lane & 15;
         for (int j = 0; j < 16; ++j) {
             const int n = t + 16 * j;

@@ -82,8 +82,8 @@ def test_config2_full_batch_on_the_fused_f64_path(P):
     """Config 2 as BASELINE.json states it -- 512 slices of 256x256, Q_Random30, S4:176 presets, 100 CNC
     iterations -- on the fused double-precision path: (a) every slice agrees with the generic double
     kernels (a different FFT factorisation and data flow) to 1e-9; (b) slices 0, 255 and 511 agree
-    with the float64 oracle to 1e-8, three orders inside the north star's 1e-5; (c) odd batches and a
-    run split into two calls give the same result."""
+    with the float64 oracle to 1e-8, three orders inside the north star's 1e-5; (c) a run split into two
+    calls gives the same bits, an odd batch the same result."""
     from pnp_admm_cnc_mri_amd import synthetic as S
     B = 512
     mask = S.reference_masks()['Q_Random30'].astype(np.uint8)
@@ -115,4 +115,6 @@ def test_config2_full_batch_on_the_fused_f64_path(P):
         eng.upload(ys[:7], mask)
         eng.init_state()
         eng.admm_cnc(100, 0.45, 0.5, 0.05, 64)
-        assert np.array_equal(eng.x(), res[1][:7])
+        x7 = eng.x()
+    assert np.array_equal(x7[:6], res[1][:6])                  # same pairs -> same bits
+    assert rel_l2(x7[6], res[1][6]) <= 1e-9                    # slice 6 lost its partner in the shared complex transform: round-off only
