@@ -206,6 +206,9 @@ __device__ __forceinline__ void col5_b(c32 (&a)[16], const c32* twl, c32* region
     fft512_b2<INV>(a, twl, t);
 }
 
+#ifdef F512_COLS_W3          // experiment knob: cap the column kernel at 168 VGPRs (3 waves per SIMD); spills 92 B/lane
+__attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 __global__ __launch_bounds__(256) void k5_cols(F5ColArgs p) {
     __shared__ __attribute__((aligned(16))) c32 lds[COLS5_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

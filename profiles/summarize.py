@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'gpurun_out')
-LOOP = ('k_frows', 'k_fcols', 'k_fmixed', 'k5_rows', 'k5_cols', 'k_slice', 'k_rows', 'k_cols')
+LOOP = ('k_frows', 'k_fcols', 'k_fmixed', 'k5_rows', 'k5_cols', 'k_slice')     # the generic path's loop kernels: by call count
 
 
 def short(name):
@@ -67,7 +67,8 @@ def one(tag, name):
     bk, bp = bench.get('kt', {}), bench.get('fetch', {})
     it_kt = bk.get('steps', 100) + bk.get('warmup', 10)
     it_pmc = bp.get('steps', 20) + bp.get('warmup', 2)
-    loop = [s for s in stats if any(s['kernel'].startswith(p) for p in LOOP)]
+    generic = bk.get('config', {}).get('path') == 'generic'
+    loop = [s for s in stats if (s['calls'] >= 50 if generic else any(s['kernel'].startswith(p) for p in LOOP))]
     hbm_it = sum((2.0 * pmc[s['kernel']].get('FETCH_SIZE_KiB_total', 0) + pmc[s['kernel']].get('WRITE_SIZE_KiB_total', 0)) * 1024
                  for s in loop if s['kernel'] in pmc) / it_pmc
     B = bk.get('config', {}).get('slices_per_gpu', 512)
