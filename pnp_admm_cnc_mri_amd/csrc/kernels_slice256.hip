@@ -170,16 +170,24 @@ __device__ __forceinline__ void dft16_lp(c32 (&a)[16]) {
 // 16-lane FFT-256 on a[16] (lane t holds index t + 16 j), exchange through the group's region
 template <bool INV>
 __device__ __forceinline__ void group_fft256(c32 (&a)[16], const c32* twl, c32* region, int t) {
-    SLICE_DFT16<INV>(a);
-    // twl is stored per lane: twl[16 t + k] = W256^(t k): one address register + immediate offsets,
-    // fetched after the butterflies (not piled up in registers before them)
-    mem_fence_compiler();
+    // twl is stored per lane: twl[16 t + k] = W256^(t k): one address register + immediate offsets
     const c32* tw = twl + 16 * t;
+#ifdef SLICE_TW_EARLY
+    c32 twr[16];                                   // experiment knob: issue the 15 twiddle reads before the butterflies
+#pragma unroll
+    for (int k = 1; k < 16; ++k) twr[k] = tw[k];
+    SLICE_DFT16<INV>(a);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twr[k]);
+#else
+    SLICE_DFT16<INV>(a);
+    mem_fence_compiler();                          // fetched after the butterflies (not piled up in registers before them)
 #pragma unroll
     for (int k = 1; k < 8; ++k) a[k] = tmul<INV>(a[k], tw[k]);
     mem_fence_compiler();
 #pragma unroll
     for (int k = 8; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[k]);
+#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) region[k * 17 + t] = a[k];
     wave_sync();
