@@ -10,7 +10,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpnpmri.so')
+# PNP_MRI_LIB: developer knob for A/B runs of two builds of the library; the product ships the in-tree one
+LIB_PATH = os.environ.get('PNP_MRI_LIB') or os.path.join(_HERE, 'libpnpmri.so')
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)

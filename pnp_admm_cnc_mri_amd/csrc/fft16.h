@@ -108,13 +108,15 @@ PNP_HD void fft256_tail(cxT<R> (&a)[16]) { dft16<INV>(a); }
 // "B" structure (k-layout in, t-layout out) is its transposed flow graph (the DFT matrix is
 // symmetric):  butterfly -> W32^(q h) -> dft16 -> exchange -> W512^(t k2) -> dft16.
 // INV conjugates every twiddle, i.e. selects the direction of the transform; both structures
-// serve both directions.  tw = W512 table (forward values); W32^(q h) comes from literals.
+// serve both directions.  twt = the lane's row of the W512^(t k) table (forward values); W32^(q h) comes from literals.
 // ----------------------------------------------------------------------------------------------
+// twt: the lane's 16 twiddles, twt[k] = W512^(t k) (a per-lane row of a [32][16] table: one address
+// register + immediate offsets instead of 15 computed addresses)
 template <bool INV>
-PNP_HD void fft512_a1(c32 (&a)[16], const c32* tw, int t) {            // before the exchange
+PNP_HD void fft512_a1(c32 (&a)[16], const c32* twt) {                  // before the exchange
     dft16<INV>(a);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[t * k]);
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twt[k]);
 }
 // W32^q = exp(-2 pi i q / 32) as compile-time constants (instruction literals: no table read, no
 // register held); the h = 0 lane multiplies by 1.
@@ -138,9 +140,9 @@ PNP_HD void fft512_b1(c32 (&a)[16], int h) {                          // after t
     dft16<INV>(a);
 }
 template <bool INV>
-PNP_HD void fft512_b2(c32 (&a)[16], const c32* tw, int t) {            // after the exchange
+PNP_HD void fft512_b2(c32 (&a)[16], const c32* twt) {                  // after the exchange
 #pragma unroll
-    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], tw[t * k]);
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twt[k]);
     dft16<INV>(a);
 }
 

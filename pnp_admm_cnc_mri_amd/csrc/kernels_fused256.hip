@@ -100,7 +100,7 @@ template <bool INV, typename R>
 __device__ __forceinline__ void fft256_head_lds(cxT<R> (&a)[16], const cxT<R>* twl, int t) {
     dft16<INV>(a);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twl[t * k]);
+    for (int k = 1; k < 16; ++k) a[k] = tmul<INV>(a[k], twl[17 * t + k]);     // one address register + immediate offsets
 }
 
 constexpr int RP = 272;    // staging pitch (c32) of a row in LDS: 272 % 32 == 16 -> two rows per
@@ -121,7 +121,7 @@ __device__ __forceinline__ void row_fft256(cxT<R> (&a)[16], const cxT<R>* twl, c
 }
 
 // PROX: see fused_pointwise.h
-constexpr int ROWS_LDS = 16 * XP + 256;      // c32 elements of LDS the row body needs
+constexpr int ROWS_LDS = 16 * XP + 272;      // c32 elements of LDS the row body needs (exchange regions + 16 x 17 twiddle rows)
 
 template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 __device__ __forceinline__ void frows_body(const FRowArgsT<R>& p, const int bid, cxT<R>* lds) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ void frows_body(const FRowArgsT<R>& p, const int bid,
     constexpr int NU = 16 * UPR / 256;                   // accesses per thread for the block's 16 rows
     const int tid = threadIdx.x, g = tid >> 4, t = tid & 15;
     C* twl = lds + 16 * XP;                    // W256 table (read where used, not held in VGPRs)
-    twl[tid] = tw_table<R>()[tid];
+    twl[17 * (tid >> 4) + (tid & 15)] = tw_table<R>()[((tid >> 4) * (tid & 15)) & 255];   // [t][k] = W256^(t k), rows of 17: conflict-free
     const int pair = bid >> 4, r0 = (bid & 15) * 16;
     const int sa = 2 * pair, sb = sa + 1;
     const bool has_b = sb < p.B;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void col_exchange(cxT<R> (&a)[16], cxT<R>* region, in
     __syncthreads();
 }
 
-constexpr int COLS_LDS = 16 * CP + 256;
+constexpr int COLS_LDS = 16 * CP + 272;
 
 __device__ __forceinline__ void fcols_body(const FColArgs& p, const int bid, c32* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void fcols_body(const FColArgs& p, const int bid, c32
     // W256 table in LDS: twiddles are fetched where they are used (ds_read_b64, 4 distinct
     // addresses per wave) instead of occupying 32 VGPRs for the whole kernel
     c32* twl = lds + 16 * CP;
-    twl[tid] = g_twf[tid];
+    twl[17 * (tid >> 4) + (tid & 15)] = g_twf[((tid >> 4) * (tid & 15)) & 255];            // [t][k] = W256^(t k), rows of 17: conflict-free
     c32 P[16], Q[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_fcols2(FCol2Args<R> p) {
     const int phys = self ? kl : 2 * (8 * m + kl) + s;
     C* Tp = p.T + (size_t)pair * 65536 + phys;
     C* twl = lds + 16 * CP;
-    twl[tid] = tw_table<R>()[tid];
+    twl[17 * (tid >> 4) + (tid & 15)] = tw_table<R>()[((tid >> 4) * (tid & 15)) & 255];   // [t][k] = W256^(t k), rows of 17: conflict-free
     C a[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[j] = valid ? Tp[(t + 16 * j) * 256] : mk<R>((R)0, (R)0);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k5_prepare(const c32* y, const uint8_t* m
 
 constexpr int RP5 = 520;     // LDS pitch (c32) of a staged row
 constexpr int XP5 = 544;     // exchange region per 32-lane group: 16 runs of 34
-constexpr int ROWS5_LDS = 8 * XP5 + 512;
+constexpr int ROWS5_LDS = 8 * XP5 + 544;
 
 // exchanges between the lanes of one 32-lane group through its LDS region (block barriers: all
 // 8 groups of the workgroup exchange together)
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
     const int tid = threadIdx.x, g = tid >> 5, t = tid & 31;
     const int k2 = t >> 1, h = t & 1;
     c32* twl = lds + 8 * XP5;
-    twl[tid] = g_tw512f[tid];
-    twl[tid + 256] = g_tw512f[tid + 256];
+    twl[17 * (tid >> 4) + (tid & 15)] = g_tw512f[((tid >> 4) * (tid & 15)) & 511];     // [t : 32][k : 16] = W512^(t k), rows of 17: conflict-free
+    twl[17 * ((tid >> 4) + 16) + (tid & 15)] = g_tw512f[(((tid >> 4) + 16) * (tid & 15)) & 511];
     const int pair = blockIdx.x >> 6, r0 = (blockIdx.x & 63) * 8;
     const int sa = 2 * pair, sb = sa + 1;
     const bool has_b = sb < p.B;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
         for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_quad_swap1(a[q].x), dpp_quad_swap1(a[q].y)), h);
         fft512_b1<true>(a, h);
         xchg_k2t(a, region, t);
-        fft512_b2<true>(a, twl, t);
+        fft512_b2<true>(a, twl + 17 * t);
 #pragma unroll
         for (int j = 0; j < 16; ++j) lds[g * RP5 + t + 32 * j] = a[j];
         __syncthreads();
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
         for (int j = 0; j < 16; ++j) a[j] = lds[g * RP5 + t + 32 * j];
         __syncthreads();
         // structure A, forward direction: t-layout -> k-layout
-        fft512_a1<false>(a, twl, t);
+        fft512_a1<false>(a, twl + 17 * t);
         xchg_t2k(a, region, t);
         fft512_a2<false>(a, h);
 #pragma unroll
@@ -185,12 +185,12 @@ struct F5ColArgs {
 };
 
 constexpr int CP5 = 548;     // exchange region (c32) per column group
-constexpr int COLS5_LDS = 8 * CP5 + 512;
+constexpr int COLS5_LDS = 8 * CP5 + 544;
 
 template <bool INV>
 __device__ __forceinline__ void col5_a(c32 (&a)[16], const c32* twl, c32* region, int t) {     // t-layout -> k-layout
     const int h = t & 1;
-    fft512_a1<INV>(a, twl, t);
+    fft512_a1<INV>(a, twl + 17 * t);
     xchg_t2k(a, region, t);
     fft512_a2<INV>(a, h);
 #pragma unroll
@@ -203,7 +203,7 @@ __device__ __forceinline__ void col5_b(c32 (&a)[16], const c32* twl, c32* region
     for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk(dpp_row_ror8(a[q].x), dpp_row_ror8(a[q].y)), h);
     fft512_b1<INV>(a, h);
     xchg_k2t(a, region, t);
-    fft512_b2<INV>(a, twl, t);
+    fft512_b2<INV>(a, twl + 17 * t);
 }
 
 #ifdef F512_COLS_W3          // experiment knob: cap the column kernel at 168 VGPRs (3 waves per SIMD); spills 92 B/lane
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256) void k5_cols(F5ColArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kl = lane & 7, tq = lane >> 3, t = 8 * wv + tq;       // lanes t and t^1 sit 8 apart in one DPP row
     c32* twl = lds + 8 * CP5;
-    twl[tid] = g_tw512f[tid];
-    twl[tid + 256] = g_tw512f[tid + 256];
+    twl[17 * (tid >> 4) + (tid & 15)] = g_tw512f[((tid >> 4) * (tid & 15)) & 511];     // [t : 32][k : 16] = W512^(t k), rows of 17: conflict-free
+    twl[17 * ((tid >> 4) + 16) + (tid & 15)] = g_tw512f[(((tid >> 4) + 16) * (tid & 15)) & 511];
     const int pair = blockIdx.x / 33, m = blockIdx.x % 33;
     // tiles 0..31: column pairs q = 8 m + kl (q >= 1) = physical columns (2q, 2q+1);
     // tile 32: the two self-mirrored columns 0 and 256 (physical 0 and 1), one lane group each.

@@ -52,7 +52,7 @@ struct SliceArgs {
     const uint32_t* Mh;       // [B] x MH3_SLICE
     const c32* Ys;            // [B][256]   k2 = 128
     const uint32_t* Ms;       // [B][16]
-    int B, iters;
+    int first, B, iters;      // slices [first, first + B) of the arrays; iterations of this launch
     float scale, c;
     ProxCoef prox;
     int stagger_ticks;        // start delay step (wall_clock64 ticks, 100 MHz): workgroup b waits (b & 3) steps
@@ -60,7 +60,7 @@ struct SliceArgs {
 };
 
 constexpr int WREG = 4 * 272;                 // complex elements of a wave's private LDS region: 4 transform groups x (16 runs of 17)
-constexpr int SL_LDS = SL_BUF + 256;           // transposition buffer (the 8 wave regions alias its start) + W256 table
+constexpr int SL_LDS = SL_BUF + 272;           // transposition buffer (the 8 wave regions alias its start) + W256 table
 static_assert(SL_WAVES * WREG <= SL_BUF, "wave regions must fit in the buffer they alias");
 
 // wave-synchronous ordering of LDS traffic: a wave's LDS instructions execute in order, so no
@@ -170,8 +170,9 @@ __device__ __forceinline__ void dft16_lp(c32 (&a)[16]) {
 // 16-lane FFT-256 on a[16] (lane t holds index t + 16 j), exchange through the group's region
 template <bool INV>
 __device__ __forceinline__ void group_fft256(c32 (&a)[16], const c32* twl, c32* region, int t) {
-    // twl is stored per lane: twl[16 t + k] = W256^(t k): one address register + immediate offsets
-    const c32* tw = twl + 16 * t;
+    // twl is stored per lane in rows of 17: twl[17 t + k] = W256^(t k): one address register + immediate offsets,
+    // and the 16 lanes of a group hit 16 different banks (rows of 16 would be an 8-way conflict)
+    const c32* tw = twl + 17 * t;
 #ifdef SLICE_TW_EARLY
     c32 twr[16];                                   // experiment knob: issue the 15 twiddle reads before the butterflies
 #pragma unroll
@@ -225,8 +226,11 @@ __device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L,
 // Pointwise phase of ONE row pair for 4 consecutive pixels per lane; the arithmetic of pointwise4
 // (fused_pointwise.h) operation for operation, with re = image row 2rr and im = row 2rr + 1 of the same slice.
 // cell: the 4 complex LDS values (x in, v out); voff = 16 lane; soff = byte offset of row 2rr in the slice.
-template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32* cell,
+// `last` (wave-uniform, run time): the final iteration of a launch stores z, w AND x; the loop has ONE row-phase body
+// for all its iterations (the kernel is 100+ KB of code and the instruction cache 64 KB), at the price of one
+// unused forward transform per launch.
+template <bool HAS_INV, int PROX, bool HAS_FWD>
+__device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32* cell,
                                                   int voff, int soff, float (&za)[4], float (&wa)[4], float (&zb)[4], float (&wb)[4]) {
     const int soffb = soff + 1024;
     float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
@@ -251,7 +255,7 @@ __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const Prox
             za[q] = soft_thr(ua[q], pc.thr); wa[q] = ua[q] - za[q];
             zb[q] = soft_thr(ub[q], pc.thr); wb[q] = ub[q] - zb[q];
         }
-        if (HAS_FWD) {
+        if (!last) {
             st4(b.w, voff, soff, ua);
             st4(b.w, voff, soffb, ub);
         } else {
@@ -268,7 +272,7 @@ __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const Prox
         st4(b.z, voff, soff, za); st4(b.w, voff, soff, wa);
         st4(b.z, voff, soffb, zb); st4(b.w, voff, soffb, wb);
     }
-    if (WRITE_X) {
+    if (HAS_INV && last) {
         st4(b.x, voff, soff, xa);
         st4(b.x, voff, soffb, xb);
     }
@@ -279,8 +283,8 @@ __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const Prox
 }
 
 // all four register sets of a wave; loads of set s + 1 are in flight during the transforms around them
-template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
-__device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, c32 (&F)[SL_SETS][16],
+template <bool HAS_INV, int PROX, bool HAS_FWD>
+__device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32 (&F)[SL_SETS][16],
                                           c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * 272;
@@ -304,7 +308,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int soff = (2 * (32 * set + 4 * wv + i)) * 1024;
-            pointwise_rowpair<HAS_INV, PROX, HAS_FWD, WRITE_X>(b, pc, scale, u_first, wreg + i * 272 + 4 * lane, 16 * lane, soff,
+            pointwise_rowpair<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, wreg + i * 272 + 4 * lane, 16 * lane, soff,
                                                                L.za[i], L.wa[i], L.zb[i], L.wb[i]);
         }
         if (set + 1 < SL_SETS) issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, set + 1, wv, lane);
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index as a scalar: bases below stay in SGPRs
     c32* twl = lds + SL_BUF;
-    if (tid < 256) twl[tid] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k)
+    if (tid < 256) twl[17 * (tid >> 4) + (tid & 15)] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k), rows of 17: bank-conflict free
     c32* wreg = lds + wv * WREG;
     if (p.stagger_ticks > 0) {
         // Equal workgroups started together run their HBM-heavy row phases together, chip-wide.  A one-time
@@ -468,16 +472,17 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
         while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
     __syncthreads();
-    for (int slice = blockIdx.x; slice < p.B; slice += gridDim.x) {
+    for (int sb = blockIdx.x; sb < p.B; sb += gridDim.x) {
+        const int slice = p.first + sb;
         const size_t so = (size_t)slice * 65536;
         SliceBufs b;
         b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + so, 65536 * 4);
         b.yh = make_rsrc(p.Yh + (size_t)slice * YH3_SLICE, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
         b.ys = make_rsrc(p.Ys + (size_t)slice * 256, 256 * 8); b.ms = make_rsrc(p.Ms + (size_t)slice * 16, 16 * 4);
         c32 F[SL_SETS][16];
-        long long* prof = (p.prof && tid == 0 && slice == blockIdx.x) ? p.prof + (size_t)blockIdx.x * (2 + 4 * p.iters) : nullptr;
+        long long* prof = (p.prof && tid == 0 && sb == (int)blockIdx.x) ? p.prof + (size_t)slice * (2 + 4 * p.iters) : nullptr;
         if (prof) *prof++ = wall_clock64();
-        row_phase<false, 0, true, false>(b, p.prox, p.scale, 1, F, wreg, twl, wv, opaque(lane));
+        row_phase<false, 0, true>(b, p.prox, p.scale, 1, false, F, wreg, twl, wv, opaque(lane));
         if (prof) *prof++ = wall_clock64();
         for (int it = 0; it < p.iters; ++it) {
             c32 G[SL_SETS][16];
@@ -492,8 +497,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
             t2_pass<1>(G, F, lds, wv, opaque(lane));
             if (prof) *prof++ = wall_clock64();
             const int u_first = (it == 0);
-            if (it + 1 < p.iters) row_phase<true, PROX, true, false>(b, p.prox, p.scale, u_first, F, wreg, twl, wv, opaque(lane));
-            else                  row_phase<true, PROX, false, true>(b, p.prox, p.scale, u_first, F, wreg, twl, wv, opaque(lane));
+            row_phase<true, PROX, true>(b, p.prox, p.scale, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane));
             if (prof) *prof++ = wall_clock64();
         }
         __syncthreads();
@@ -535,6 +539,10 @@ struct Slice256 {
     uint32_t* Mh = nullptr;
     c32* Ys = nullptr;
     uint32_t* Ms = nullptr;
+    static constexpr int MAXQ = 4;
+    hipStream_t side[MAXQ - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[MAXQ - 1] = {nullptr, nullptr, nullptr};
 };
 
 int slice256_cus(const Slice256* f) { return f && f->cus > 0 ? f->cus : 256; }
@@ -545,6 +553,11 @@ void slice256_destroy(Slice256* f) {
     if (f->Mh) (void)hipFree(f->Mh);
     if (f->Ys) (void)hipFree(f->Ys);
     if (f->Ms) (void)hipFree(f->Ms);
+    for (int q = 0; q < Slice256::MAXQ - 1; ++q) {
+        if (f->side[q]) (void)hipStreamDestroy(f->side[q]);
+        if (f->ev_join[q]) (void)hipEventDestroy(f->ev_join[q]);
+    }
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     delete f;
 }
 
@@ -586,44 +599,88 @@ hipError_t slice256_prepare(Slice256* f, hipStream_t s, const float2* y, const u
     return hipGetLastError();
 }
 
+static hipError_t launch_slice(hipStream_t s, const SliceArgs& a, int prox) {
+    // one workgroup per slice; a workgroup fills a compute unit (512 threads x 256 VGPRs, 134 KiB of LDS)
+    const dim3 grid(a.B);
+    if (prox == 2)      hipLaunchKernelGGL(k_slice<2>, grid, dim3(512), 0, s, a);
+    else if (prox == 1) hipLaunchKernelGGL(k_slice<1>, grid, dim3(512), 0, s, a);
+    else                hipLaunchKernelGGL(k_slice<3>, grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
+// Experiment knobs (PNP_SLICE_QUEUES, PNP_SLICE_SEGMENT; default: ONE launch): a run can be cut into parts of the
+// batch on several HIP queues times consecutive launches of a part of the iterations.  Workgroups differ in speed
+// by +-10 % (up to +25 %) and with two workgroups per compute unit the slowest unit sets the time of a single
+// launch (makespan 8.0 ms against 7.0 ms of balanced work at 50 iterations); smaller units were meant to even this
+// out but measured no better (6.3 k it/s for 2 queues x 16-iteration segments against 6.5 k for one launch).
+// A run split into calls is bit-identical to one call (tests), so such cuts never change results.
 hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc, float dc_c,
                         ProxParams pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
     SliceArgs a;
     a.z = z; a.w = w; a.x = x; a.Yh = f->Yh; a.Mh = f->Mh; a.Ys = f->Ys; a.Ms = f->Ms;
-    a.B = B; a.iters = iters; a.scale = 1.0f / 65536.0f; a.c = dc_c;
+    a.first = 0; a.B = B; a.iters = iters; a.scale = 1.0f / 65536.0f; a.c = dc_c;
     a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
     a.prof = nullptr;
-    {
-        const char* e = getenv("PNP_SLICE_STAGGER_US");          // default: a quarter of a slice-iteration (~20 us)
-        const double us = e ? atof(e) : 20.0;
-        a.stagger_ticks = (iters >= 4) ? (int)(us * 100.0) : 0;  // not worth it for very short runs
-    }
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    a.stagger_ticks = env_int("PNP_SLICE_STAGGER_US", 0) * 100;          // experiment knob (measured: no effect)
+    const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
+    int queues = env_int("PNP_SLICE_QUEUES", 1), seg_len = env_int("PNP_SLICE_SEGMENT", 0);   // measured: 1 launch is best
+    if (queues < 1) queues = 1;
+    if (queues > Slice256::MAXQ) queues = Slice256::MAXQ;
+    if (B < 64 * queues) queues = 1;
+    int segments = seg_len > 0 ? (iters + seg_len - 1) / seg_len : 1;
+    if (segments < 1) segments = 1;
+
     long long* d_prof = nullptr;
-    const char* prof_path = getenv("PNP_SLICE_PROF");          // debugging aid: dump per-phase clocks of each workgroup's first slice
+    const char* prof_path = getenv("PNP_SLICE_PROF");          // debugging aid: per-phase clocks of each workgroup (single launch only)
     const size_t prof_n = (size_t)B * (2 + 4 * (size_t)iters);
-    if (prof_path && hipMalloc((void**)&d_prof, prof_n * sizeof(long long)) == hipSuccess) {
-        (void)hipMemsetAsync(d_prof, 0, prof_n * sizeof(long long), s);
-        a.prof = d_prof;
+    if (prof_path) {
+        queues = 1; segments = 1;
+        if (hipMalloc((void**)&d_prof, prof_n * sizeof(long long)) == hipSuccess) {
+            (void)hipMemsetAsync(d_prof, 0, prof_n * sizeof(long long), s);
+            a.prof = d_prof;
+        }
     }
-    // one workgroup per slice; a workgroup fills a compute unit (512 threads x 256 VGPRs, 134 KiB of LDS)
-    const dim3 grid(B);
-    if (cnc)                    hipLaunchKernelGGL(k_slice<2>, grid, dim3(512), 0, s, a);
-    else if (sch.l1_two_state)  hipLaunchKernelGGL(k_slice<1>, grid, dim3(512), 0, s, a);
-    else                        hipLaunchKernelGGL(k_slice<3>, grid, dim3(512), 0, s, a);
+    hipError_t e = hipSuccess;
+    if (queues > 1) {
+        if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
+        for (int q = 0; q < queues - 1 && e == hipSuccess; ++q) {
+            if (f->side[q]) continue;
+            e = hipStreamCreateWithFlags(&f->side[q], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join[q], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventRecord(f->ev_fork, s);
+    }
+    int c0 = 0;
+    for (int q = 0; q < queues && e == hipSuccess; ++q) {
+        const int Bq = (q == queues - 1) ? (B - c0) : (B / queues);
+        hipStream_t sq = (q == 0) ? s : f->side[q - 1];
+        if (q > 0) e = hipStreamWaitEvent(sq, f->ev_fork, 0);
+        int done = 0;
+        for (int g = 0; g < segments && e == hipSuccess; ++g) {
+            const int n = (iters - done + (segments - g) - 1) / (segments - g);     // even split of what is left
+            a.first = c0; a.B = Bq; a.iters = n;
+            e = launch_slice(sq, a, prox);
+            done += n;
+        }
+        if (q > 0 && e == hipSuccess) e = hipEventRecord(f->ev_join[q - 1], sq);
+        if (q > 0 && e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join[q - 1], 0);
+        c0 += Bq;
+    }
     if (d_prof) {
         std::vector<long long> h(prof_n);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), d_prof, prof_n * sizeof(long long), hipMemcpyDeviceToHost);
         (void)hipFree(d_prof);
-        if (FILE* f = fopen(prof_path, "wb")) {
+        if (FILE* fo = fopen(prof_path, "wb")) {
             const int hdr[2] = {B, iters};
-            fwrite(hdr, sizeof(int), 2, f);
-            fwrite(h.data(), sizeof(long long), prof_n, f);
-            fclose(f);
+            fwrite(hdr, sizeof(int), 2, fo);
+            fwrite(h.data(), sizeof(long long), prof_n, fo);
+            fclose(fo);
         }
     }
-    return hipGetLastError();
+    return e;
 }
 
 }  // namespace pnp

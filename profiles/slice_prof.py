@@ -17,4 +17,25 @@ for k, n in enumerate(names):
     d = ph[:, :, k] - (prev if k == 0 else ph[:, :, k - 1])
     print('%-10s   median %.2f us   p10 %.2f  p90 %.2f' % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 print('iteration    median %.2f us' % np.median(ph[:, :, 3] - prev))
-print('start spread of workgroups %.1f us; total span %.1f us' % (t[:, 0].max() - t[:, 0].min(), t[:, -1].max() - t[:, 0].min()))
+t0 = t[:, 0].min()
+start, end = t[:, 0] - t0, t[:, -1] - t0
+dur = end - start
+print('workgroup duration: median %.1f us  p10 %.1f  p90 %.1f  max %.1f;  makespan %.1f us' % (
+    np.median(dur), np.percentile(dur, 10), np.percentile(dur, 90), dur.max(), end.max()))
+order = np.argsort(start)
+first_round = start < np.median(dur) * 0.5
+print('workgroups starting in the first half-duration: %d; their end: median %.1f  max %.1f;  the others start: min %.1f median %.1f max %.1f' % (
+    first_round.sum(), np.median(end[first_round]), end[first_round].max(),
+    start[~first_round].min() if (~first_round).any() else -1, np.median(start[~first_round]) if (~first_round).any() else -1,
+    start[~first_round].max() if (~first_round).any() else -1))
+per_it = (ph[:, :, 3] - prev)
+print('per-iteration time by iteration index (median over workgroups):', np.round(np.median(per_it, axis=0)[:12], 1))
+print('  first-round workgroups %.1f us/iteration, second-round %.1f' % (np.median(per_it[first_round]), np.median(per_it[~first_round]) if (~first_round).any() else -1))
+
+# which workgroups are slow?  blocks b and b + 8 share an XCD (round-robin dispatch): per-residue medians
+raw_all = np.frombuffer(raw[8:], np.int64).reshape(B, 2 + 4 * iters).astype(np.float64) / 100.0
+d_all = raw_all[:, -1] - raw_all[:, 0]
+for rnd, sel in (('first 256 blocks', slice(0, 256)), ('blocks 256..', slice(256, None))):
+    dd = d_all[sel]
+    if len(dd):
+        print(rnd, 'duration by blockIdx %% 8:', np.round([np.median(dd[r::8]) for r in range(8)], 0))

@@ -15,7 +15,8 @@ static void coop_a(std::vector<c32>& v, bool inv) {
     for (int t = 0; t < 32; ++t) {
         c32 a[16];
         for (int j = 0; j < 16; ++j) a[j] = v[t + 32 * j];
-        if (inv) fft512_a1<true>(a, TW, t); else fft512_a1<false>(a, TW, t);
+        c32 twt[16]; for (int k = 0; k < 16; ++k) twt[k] = TW[(t * k) & 511];      // the lane's row of the W512^(t k) table
+        if (inv) fft512_a1<true>(a, twt); else fft512_a1<false>(a, twt);
         for (int k2 = 0; k2 < 16; ++k2) lds[k2 * 34 + t] = a[k2];
     }
     for (int L = 0; L < 32; ++L) {
@@ -48,7 +49,8 @@ static void coop_b(std::vector<c32>& v, bool inv) {
     for (int t = 0; t < 32; ++t) {
         c32 a[16];
         for (int k2 = 0; k2 < 16; ++k2) a[k2] = lds[k2 * 34 + t];
-        if (inv) fft512_b2<true>(a, TW, t); else fft512_b2<false>(a, TW, t);
+        c32 twt[16]; for (int k = 0; k < 16; ++k) twt[k] = TW[(t * k) & 511];
+        if (inv) fft512_b2<true>(a, twt); else fft512_b2<false>(a, twt);
         for (int j = 0; j < 16; ++j) v[t + 32 * j] = a[j];
     }
 }
