@@ -16,6 +16,13 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifndef F512_ROWS_W
+#define F512_ROWS_W 3       // waves per SIMD of the row / column kernels (experiment knobs; the defaults are the measured best)
+#endif
+#ifndef F512_COLS_W
+#define F512_COLS_W 2
+#endif
+
 namespace pnp {
 
 __device__ c32 g_tw512f[512];
@@ -105,7 +112,10 @@ __device__ __forceinline__ void xchg_k2t(c32 (&a)[16], c32* region, int t) {
 }
 
 // PROX as in kernels_fused256.hip: 0 none, 1 L1 (z and w), 2 CNC, 3 L1 single-state
+// 3 waves per SIMD on purpose: with the per-lane twiddle rows the kernel needs <= 128 VGPRs and would run 4, which
+// measured 3 % SLOWER on one box (1032 vs 1065 it/s at 256 slices) -- these strided, HBM-bound kernels do not want more waves
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+__attribute__((amdgpu_waves_per_eu(F512_ROWS_W, F512_ROWS_W)))
 __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
     __shared__ __attribute__((aligned(16))) c32 lds[ROWS5_LDS];
     const int tid = threadIdx.x, g = tid >> 5, t = tid & 31;
@@ -206,9 +216,8 @@ __device__ __forceinline__ void col5_b(c32 (&a)[16], const c32* twl, c32* region
     fft512_b2<INV>(a, twl + 17 * t);
 }
 
-#ifdef F512_COLS_W3          // experiment knob: cap the column kernel at 168 VGPRs (3 waves per SIMD); spills 92 B/lane
-__attribute__((amdgpu_waves_per_eu(3, 3)))
-#endif
+// 2 waves per SIMD on purpose (162 VGPRs would allow 3; measured slower, see k5_rows)
+__attribute__((amdgpu_waves_per_eu(F512_COLS_W, F512_COLS_W)))
 __global__ __launch_bounds__(256) void k5_cols(F5ColArgs p) {
     __shared__ __attribute__((aligned(16))) c32 lds[COLS5_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
