@@ -529,9 +529,10 @@ def test_prox_edge_values(P, torch):
 
 
 def test_schedules_are_bit_identical(P):
-    """The batch may be split over HIP queues (PNP_FUSED_STREAMS) and row/column workgroups of
-    different halves may share one launch (PNP_FUSED_SCHED=1): scheduling only -- every slice
-    sees the same arithmetic, so all schedules give the same bits."""
+    """Two-launch path (PNP_SLICE=0; a batch of 131 would otherwise run slice-resident): the batch may be
+    split over HIP queues (PNP_FUSED_STREAMS) and row/column workgroups of different halves may share one
+    launch (PNP_FUSED_SCHED=1): scheduling only -- every slice sees the same arithmetic, so all schedules
+    give the same bits."""
     import os
     import subprocess
     import sys
@@ -549,7 +550,7 @@ def test_schedules_are_bit_identical(P):
     for sched, streams, chunk in (('0', '1', '0'), ('1', '1', '0'), ('0', '2', '0'), ('1', '2', '0'), ('0', '3', '0'), ('0', '1', '48')):
         path = '/tmp/sched_%s_%s_%s.npz' % (sched, streams, chunk)
         subprocess.check_call([sys.executable, '-c', code, path],
-                              env=dict(os.environ, PNP_FUSED_SCHED=sched, PNP_FUSED_STREAMS=streams, PNP_FUSED_CHUNK=chunk))
+                              env=dict(os.environ, PNP_SLICE='0', PNP_FUSED_SCHED=sched, PNP_FUSED_STREAMS=streams, PNP_FUSED_CHUNK=chunk))
         outs.append(np.load(path))
     for o in outs[1:]:
         for k in ('x', 'z', 'w', 'xl'):
