@@ -4,7 +4,8 @@
 // per slice-iteration are the transposed field T going out after the row pass and coming back for
 // the column pass.  A CU of MI355X has a 512 KiB vector register file and 160 KiB of LDS: one REAL
 // 256x256 slice (256 KiB as 128 packed complex rows, or as 128 half-plane complex columns) fits in
-// the registers of a 1024-thread workgroup (64 VGPRs per thread), and LDS is large enough to turn
+// the registers of one workgroup -- 512 threads x 256 VGPRs = the whole register file of the CU, 128 of them
+// per thread holding data (four "register sets" of 16 complex values) -- and LDS is large enough to turn
 // rows into columns in two passes.  So here ONE workgroup owns ONE slice for all iterations of a
 // run and T never exists in memory:
 //
@@ -18,12 +19,13 @@
 //                               (127 half-plane columns + the packed column {k2 = 0, k2 = 128})
 //     T2  column form -> row form, complex-to-real repack on the way
 //     rows                      inverse FFT-256 -> x = |re|, |im| / N -> L1 / CNC z-update + dual update
-//                               -> v = z - w -> FFT-256          (S4:119-132; the last one writes x instead)
+//                               -> v = z - w -> FFT-256          (S4:119-132; the last iteration also writes x)
 //
 // Row and column phases are wave-local (a 16-lane transform group never leaves its wave, each wave
-// has its own LDS region), so the 16 waves of the workgroup drift apart and cover each other's HBM
+// has its own LDS region), so the 8 waves of the workgroup drift apart and cover each other's HBM
 // latency; only the two transpositions are workgroup barriers.  Same arithmetic cores as the fused
 // path (fft16.h, fused_pointwise.h); index maps verified on the CPU by tests/host/slice_resident_emulation.cpp.
+// Measurements, the road here and the dead ends: DESIGN.md section 4.1.
 #include "internal.h"
 #include "fused_layout.h"
 #include "slice_layout.h"
@@ -55,7 +57,7 @@ struct SliceArgs {
     int first, B, iters;      // slices [first, first + B) of the arrays; iterations of this launch
     float scale, c;
     ProxCoef prox;
-    int stagger_ticks;        // start delay step (wall_clock64 ticks, 100 MHz): workgroup b waits (b & 3) steps
+    int stagger_ticks;        // experiment knob: start delay step (wall_clock64 ticks, 100 MHz), workgroup b waits (b & 3) steps
     long long* prof;          // optional phase clock dump (PNP_SLICE_PROF): [block][1 + 4 per iteration] of wall_clock64()
 };
 
@@ -90,9 +92,9 @@ typedef __amdgpu_buffer_rsrc_t bufrsrc;
 __device__ __forceinline__ bufrsrc make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-// State loads carry sc1 (aux bit 4): they are served by L2, not by the CU's vector L1.  The loop re-reads
-// z / w that THIS workgroup stored one iteration earlier inside the same launch, and a store does not
-// refresh a line the L1 still holds from the earlier load (seen on the GPU as a few stale 64-byte sectors).
+// State loads carry sc1 (aux bit 4): they are served by L2, not by the CU's vector L1 -- the loop re-reads
+// z / w that THIS workgroup stored one iteration earlier inside the same launch (defensive: the vector L1 is
+// not refreshed by stores; costs nothing measurable on 16-byte streaming loads).
 __device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]) {
 #ifdef SLICE_ABLATE_ROWMEM          // timing experiment only (results are wrong)
     v[0] = v[1] = v[2] = v[3] = 0.25f; return;
@@ -128,8 +130,7 @@ struct SliceBufs {
 __device__ __forceinline__ void pin(c32& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 // keeps memory operations on their side (limits how many loads the scheduler piles up in registers)
 __device__ __forceinline__ void mem_fence_compiler() { asm volatile("" ::: "memory"); }
-// nothing is scheduled across this point: keeps the two register sets' chains from being interleaved
-// (which would double the live temporaries of a 128-VGPR kernel)
+// nothing is scheduled across this point (used by dft16_lp)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ float dpp_lane_xor1(float v) {
@@ -137,9 +138,9 @@ __device__ __forceinline__ float dpp_lane_xor1(float v) {
 }
 __device__ __forceinline__ c32 dpp_lane_xor1(c32 v) { return mk<float>(dpp_lane_xor1(v.x), dpp_lane_xor1(v.y)); }
 
-// dft16 of fft16.h, operation for operation, with the eight radix-4 butterflies kept apart by
-// scheduling barriers: hipcc otherwise interleaves them for ILP and needs ~65 temporaries; with four
-// waves per SIMD the other waves provide the parallelism, and this kernel has 64 registers of working space
+// Experiment knob (-DSLICE_DFT16=dft16_lp): dft16 of fft16.h, operation for operation, with the eight radix-4
+// butterflies kept apart by scheduling barriers (hipcc otherwise interleaves them and uses ~65 temporaries).
+// Needed by the first, 128-VGPR version of this kernel; with 256 VGPRs free interleaving is 14 % faster.
 template <bool INV>
 __device__ __forceinline__ void dft16_lp(c32 (&a)[16]) {
     const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     if (tid < 256) twl[17 * (tid >> 4) + (tid & 15)] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k), rows of 17: bank-conflict free
     c32* wreg = lds + wv * WREG;
     if (p.stagger_ticks > 0) {
-        // Equal workgroups started together run their HBM-heavy row phases together, chip-wide.  A one-time
-        // start offset of a quarter iteration per residue class spreads the phases so that HBM always has takers.
+        // experiment knob (PNP_SLICE_STAGGER_US, default off): equal workgroups started together run their HBM-heavy
+        // row phases together, chip-wide; a one-time start offset per residue class spreads them (measured: no effect)
         const long long t0 = wall_clock64(), wait = (long long)(blockIdx.x & 3) * p.stagger_ticks;
         while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }

@@ -343,3 +343,35 @@ def test_split_chain_float_engine_vs_oracle(env, golden_inputs, solver, monkeypa
         y128 = ys[b].astype(np.complex128)
         ref = O.admm_cnc(y128, masks[mid[b]], 10) if solver == 'cnc' else O.admm_l1(y128, masks[mid[b]], 10)
         assert rel_l2(x[b], ref) <= 2e-6, (b, rel_l2(x[b], ref))
+
+
+def test_config4_shard_full_batch_drunet(env):
+    """Config 4's per-GPU shard at full size: PNP_ADMM_CNC_D with DRUNet on 512 slices of 256x256, Q_Cartesian30,
+    S6:577 preset, ONE iteration (two DRUNet forwards over the whole shard).  (a) the 64 slices of one CNN batch
+    run alone are bit-equal to the same slices inside the shard; (b) oracle-loop spot check on the last slice."""
+    torch, D, S = env['torch'], env['D'], env['S']
+    from pnp_admm_cnc_mri_amd import synthetic as SY, utils_pnp
+    B = 512
+    mask = SY.reference_masks()['Q_Cartesian30'].astype(np.uint8)
+    with env['P'].Engine(256, 256, Bmax=B) as eng:
+        img, noise = SY.batch(0, B)
+        eng.synthesize(img, noise, mask)
+        ys = eng.download_y()
+    name = 'drunet_gray'
+    net, nlm, _ = D.build(name)
+    sd = D.seeded_state_dict(net, 1003)
+    opts = dict(alpha=1, iter_num=1, lambda1=0.8, reo=0.8, b=0.45)               # S6:577, 1 iteration
+    full, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys, model=sd, **opts)
+    full = np.stack(full[:B])
+    assert np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
+    sub, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[448:512], model=sd, **opts)
+    assert np.array_equal(np.stack(sub[:64]), full[448:512])
+    net.load_state_dict(sd)
+    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), 1, 49, nlm * 255., 1.0)[1])
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig).to(torch.device('cuda'))
+
+    def denoise(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return den(t, i)[0, 0].cpu().numpy()
+    ref = O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), mask, denoise, 1, 1, 0.8, 0.8, 0.45)
+    assert rel_l2(full[B - 1], ref) <= 1e-5, rel_l2(full[B - 1], ref)
