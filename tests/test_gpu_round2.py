@@ -345,6 +345,9 @@ def test_split_chain_float_engine_vs_oracle(env, golden_inputs, solver, monkeypa
         assert rel_l2(x[b], ref) <= 2e-6, (b, rel_l2(x[b], ref))
 
 
+@pytest.mark.skipif(os.environ.get('PNP_RUN_SLOW') != '1',
+                    reason='10 minutes on a fresh box: MIOpen compiles DRUNet\'s batch-64 convolutions first (612 s measured, '
+                           'the test itself ~15 s); run with PNP_RUN_SLOW=1.  bench_pnp.py exercises the same shard.')
 def test_config4_shard_full_batch_drunet(env):
     """Config 4's per-GPU shard at full size: PNP_ADMM_CNC_D with DRUNet on 512 slices of 256x256, Q_Cartesian30,
     S6:577 preset, ONE iteration (two DRUNet forwards over the whole shard).  (a) the 64 slices of one CNN batch
