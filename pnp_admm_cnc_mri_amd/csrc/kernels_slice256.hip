@@ -58,7 +58,7 @@ struct SliceArgs {
     float scale, c;
     ProxCoef prox;
     int stagger_ticks;        // experiment knob: start delay step (wall_clock64 ticks, 100 MHz), workgroup b waits (b & 3) steps
-    long long* prof;          // optional phase clock dump (PNP_SLICE_PROF): [block][1 + 4 per iteration] of wall_clock64()
+    long long* prof;          // optional phase clock dump (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
 };
 
 constexpr int WREG = 4 * 272;                 // complex elements of a wave's private LDS region: 4 transform groups x (16 runs of 17)
@@ -481,17 +481,19 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
         b.yh = make_rsrc(p.Yh + (size_t)slice * YH3_SLICE, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
         b.ys = make_rsrc(p.Ys + (size_t)slice * 256, 256 * 8); b.ms = make_rsrc(p.Ms + (size_t)slice * 16, 16 * 4);
         c32 F[SL_SETS][16];
-        long long* prof = (p.prof && tid == 0 && sb == (int)blockIdx.x) ? p.prof + (size_t)slice * (2 + 4 * p.iters) : nullptr;
+        long long* prof = (p.prof && tid == 0 && sb == (int)blockIdx.x) ? p.prof + (size_t)slice * (2 + 6 * p.iters) : nullptr;
         if (prof) *prof++ = wall_clock64();
         row_phase<false, 0, true>(b, p.prox, p.scale, 1, false, F, wreg, twl, wv, opaque(lane));
         if (prof) *prof++ = wall_clock64();
         for (int it = 0; it < p.iters; ++it) {
             c32 G[SL_SETS][16];
             __syncthreads();                      // every wave is done with its private region: the buffer aliases them
+            if (prof) *prof++ = wall_clock64();   // wave 0's wait for the slowest wave of the row phase ends here
             t1_pass<0>(F, G, lds, wv, opaque(lane));
             t1_pass<1>(F, G, lds, wv, opaque(lane));
             if (prof) *prof++ = wall_clock64();
             col_phase(b, p.c, G, wreg, twl, wv, opaque(lane));
+            if (prof) *prof++ = wall_clock64();
             __syncthreads();
             if (prof) *prof++ = wall_clock64();
             t2_pass<0>(G, F, lds, wv, opaque(lane));
@@ -635,7 +637,7 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
 
     long long* d_prof = nullptr;
     const char* prof_path = getenv("PNP_SLICE_PROF");          // debugging aid: per-phase clocks of each workgroup (single launch only)
-    const size_t prof_n = (size_t)B * (2 + 4 * (size_t)iters);
+    const size_t prof_n = (size_t)B * (2 + 6 * (size_t)iters);
     if (prof_path) {
         queues = 1; segments = 1;
         if (hipMalloc((void**)&d_prof, prof_n * sizeof(long long)) == hipSuccess) {

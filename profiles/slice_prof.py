@@ -5,18 +5,18 @@ import sys
 import numpy as np
 raw = open(sys.argv[1], 'rb').read()
 B, iters = np.frombuffer(raw[:8], np.int32)
-t = np.frombuffer(raw[8:], np.int64).reshape(B, 2 + 4 * iters).astype(np.float64) / 100.0   # us
+t = np.frombuffer(raw[8:], np.int64).reshape(B, 2 + 6 * iters).astype(np.float64) / 100.0   # us
 t = t[t[:, 0] > 0]
 print('workgroups with a record:', len(t), 'iterations', iters)
 first = t[:, 1] - t[:, 0]
-ph = t[:, 2:].reshape(len(t), iters, 4)
-prev = np.concatenate([t[:, 1:2], ph[:, :-1, 3]], axis=1)
-names = ['T1', 'columns', 'T2', 'rows']
+ph = t[:, 2:].reshape(len(t), iters, 6)
+prev = np.concatenate([t[:, 1:2], ph[:, :-1, 5]], axis=1)
+names = ['wait(rows)', 'T1', 'columns', 'wait(cols)', 'T2', 'rows']
 print('rows(first)  median %.2f us' % np.median(first))
 for k, n in enumerate(names):
     d = ph[:, :, k] - (prev if k == 0 else ph[:, :, k - 1])
     print('%-10s   median %.2f us   p10 %.2f  p90 %.2f' % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
-print('iteration    median %.2f us' % np.median(ph[:, :, 3] - prev))
+print('iteration    median %.2f us' % np.median(ph[:, :, 5] - prev))
 t0 = t[:, 0].min()
 start, end = t[:, 0] - t0, t[:, -1] - t0
 dur = end - start
@@ -28,12 +28,12 @@ print('workgroups starting in the first half-duration: %d; their end: median %.1
     first_round.sum(), np.median(end[first_round]), end[first_round].max(),
     start[~first_round].min() if (~first_round).any() else -1, np.median(start[~first_round]) if (~first_round).any() else -1,
     start[~first_round].max() if (~first_round).any() else -1))
-per_it = (ph[:, :, 3] - prev)
+per_it = (ph[:, :, 5] - prev)
 print('per-iteration time by iteration index (median over workgroups):', np.round(np.median(per_it, axis=0)[:12], 1))
 print('  first-round workgroups %.1f us/iteration, second-round %.1f' % (np.median(per_it[first_round]), np.median(per_it[~first_round]) if (~first_round).any() else -1))
 
 # which workgroups are slow?  blocks b and b + 8 share an XCD (round-robin dispatch): per-residue medians
-raw_all = np.frombuffer(raw[8:], np.int64).reshape(B, 2 + 4 * iters).astype(np.float64) / 100.0
+raw_all = np.frombuffer(raw[8:], np.int64).reshape(B, 2 + 6 * iters).astype(np.float64) / 100.0
 d_all = raw_all[:, -1] - raw_all[:, 0]
 for rnd, sel in (('first 256 blocks', slice(0, 256)), ('blocks 256..', slice(256, None))):
     dd = d_all[sel]
