@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256) void k_copy(const float4* z, float4* w, size_t
 }
 
 int main(int argc, char** argv) {
-    const size_t bytes = (size_t)128 << 20, n = bytes / 16;
+    const size_t mib = argc > 1 ? (size_t)atoi(argv[1]) : 128;       // MiB per array (three arrays)
+    const size_t bytes = mib << 20, n = bytes / 16;
     const int reps = 50;
     float4 *z, *w, *y; float* out;
     CK(hipMalloc(&z, bytes)); CK(hipMalloc(&w, bytes)); CK(hipMalloc(&y, bytes)); CK(hipMalloc(&out, 4));
     CK(hipMemset(z, 0, bytes)); CK(hipMemset(w, 0, bytes)); CK(hipMemset(y, 0, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("{");
+    printf("{\"MiB_per_array\": %zu, ", mib);
     const int grids[] = {256 * 4, 256 * 8, 256 * 16, 256 * 32};
     for (int gi = 0; gi < 4; ++gi) {
         const int g = grids[gi];
