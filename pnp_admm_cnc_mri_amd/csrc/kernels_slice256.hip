@@ -260,62 +260,84 @@ __device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L,
     }
 }
 
+// soft(a, c) = a - clamp(a, -c, c): the value of soft_thr (fft16.h) bit for bit (only a zero's sign can differ), as one
+// v_med3_f32 per pixel and one packed subtraction per pixel pair instead of compare / select chains
+__device__ __forceinline__ f2 clamp2(f2 a, float c) {
+    return k2(__builtin_amdgcn_fmed3f(a.x, -c, c), __builtin_amdgcn_fmed3f(a.y, -c, c));
+}
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return k2(v, v); }
+// z / w updates of TWO neighbouring pixels of one image row (prox_l1_pt / prox_cnc_pt of fft16.h, same operation order)
+template <int PROX>
+__device__ __forceinline__ void prox_pair(f2 x, f2& z, f2& w, const ProxCoef& pc) {
+    const f2 u = x + w;
+    if (PROX == 2) {
+        const f2 cz = clamp2(z, pc.ib);                                          // z - soft(z, 1/b)
+        const f2 t = fma2(splat(pc.c1), z, fma2(splat(pc.c2), u, splat(pc.c3) * cz));
+        z = t - clamp2(t, pc.thr);
+    } else {
+        z = u - clamp2(u, pc.thr);
+    }
+    w = u - z;
+}
+
 // Pointwise phase of ONE row pair for 4 consecutive pixels per lane; the arithmetic of pointwise4
-// (fused_pointwise.h) operation for operation, with re = image row 2rr and im = row 2rr + 1 of the same slice.
+// (fused_pointwise.h) with re = image row 2rr and im = row 2rr + 1 of the same slice.
 // cell: the 4 complex LDS values (x in, v out); voff = 16 lane; soff = byte offset of row 2rr in the slice.
 // `last` (wave-uniform, run time): the final iteration of a launch stores z, w AND x; the loop has ONE row-phase body
 // for all its iterations (the kernel is 100+ KB of code and the instruction cache 64 KB), at the price of one
 // unused forward transform per launch.
+// Pixels are paired (q, q + 1) WITHIN an image row: the 16-byte loads / stores are two aligned register pairs each, so
+// the packed instructions need no moves (pairing row a with row b, as hipcc does by itself, costs two per pair and array).
 template <bool HAS_INV, int PROX, bool HAS_FWD>
 __device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32* cell,
-                                                  int voff, int soff, float (&za)[4], float (&wa)[4], float (&zb)[4], float (&wb)[4]) {
+                                                  int voff, int soff, float (&za_)[4], float (&wa_)[4], float (&zb_)[4], float (&wb_)[4]) {
     const int soffb = soff + 1024;
-    float xa[4] = {0, 0, 0, 0}, xb[4] = {0, 0, 0, 0};
+    f2 za[2] = {k2(za_[0], za_[1]), k2(za_[2], za_[3])}, wa[2] = {k2(wa_[0], wa_[1]), k2(wa_[2], wa_[3])};
+    f2 zb[2] = {k2(zb_[0], zb_[1]), k2(zb_[2], zb_[3])}, wb[2] = {k2(wb_[0], wb_[1]), k2(wb_[2], wb_[3])};
+    f2 xa[2] = {splat(0.f), splat(0.f)}, xb[2] = {splat(0.f), splat(0.f)};
     if (HAS_INV) {
         const float4 c01 = *reinterpret_cast<const float4*>(cell);
         const float4 c23 = *reinterpret_cast<const float4*>(cell + 2);
-        xa[0] = fabsf(c01.x) * scale; xb[0] = fabsf(c01.y) * scale;
-        xa[1] = fabsf(c01.z) * scale; xb[1] = fabsf(c01.w) * scale;
-        xa[2] = fabsf(c23.x) * scale; xb[2] = fabsf(c23.y) * scale;
-        xa[3] = fabsf(c23.z) * scale; xb[3] = fabsf(c23.w) * scale;
+        xa[0] = k2(fabsf(c01.x) * scale, fabsf(c01.z) * scale); xb[0] = k2(fabsf(c01.y) * scale, fabsf(c01.w) * scale);
+        xa[1] = k2(fabsf(c23.x) * scale, fabsf(c23.z) * scale); xb[1] = k2(fabsf(c23.y) * scale, fabsf(c23.w) * scale);
     }
+#define SL_ST4(buf, so, v) { const float q_[4] = {v[0].x, v[0].y, v[1].x, v[1].y}; st4(buf, voff, so, q_); }
     if (PROX == 3) {                                   // ADMM_L1 single-state form: the w buffer carries u = x + w_old
-        float ua[4], ub[4];
+        f2 ua[2], ub[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2; ++q) {
             if (!u_first) {
-                wa[q] = wa[q] - soft_thr(wa[q], pc.thr);
-                wb[q] = wb[q] - soft_thr(wb[q], pc.thr);
+                wa[q] = wa[q] - (wa[q] - clamp2(wa[q], pc.thr));
+                wb[q] = wb[q] - (wb[q] - clamp2(wb[q], pc.thr));
             }
             ua[q] = xa[q] + wa[q];
             ub[q] = xb[q] + wb[q];
-            za[q] = soft_thr(ua[q], pc.thr); wa[q] = ua[q] - za[q];
-            zb[q] = soft_thr(ub[q], pc.thr); wb[q] = ub[q] - zb[q];
+            za[q] = ua[q] - clamp2(ua[q], pc.thr); wa[q] = ua[q] - za[q];
+            zb[q] = ub[q] - clamp2(ub[q], pc.thr); wb[q] = ub[q] - zb[q];
         }
         if (!last) {
-            st4(b.w, voff, soff, ua);
-            st4(b.w, voff, soffb, ub);
+            SL_ST4(b.w, soff, ua);
+            SL_ST4(b.w, soffb, ub);
         } else {
-            st4(b.z, voff, soff, za); st4(b.w, voff, soff, wa);
-            st4(b.z, voff, soffb, zb); st4(b.w, voff, soffb, wb);
+            SL_ST4(b.z, soff, za); SL_ST4(b.w, soff, wa);
+            SL_ST4(b.z, soffb, zb); SL_ST4(b.w, soffb, wb);
         }
     }
     if (PROX == 1 || PROX == 2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (PROX == 1) { prox_l1_pt(xa[q], za[q], wa[q], pc); prox_l1_pt(xb[q], zb[q], wb[q], pc); }
-            else           { prox_cnc_pt(xa[q], za[q], wa[q], pc); prox_cnc_pt(xb[q], zb[q], wb[q], pc); }
-        }
-        st4(b.z, voff, soff, za); st4(b.w, voff, soff, wa);
-        st4(b.z, voff, soffb, zb); st4(b.w, voff, soffb, wb);
+        for (int q = 0; q < 2; ++q) { prox_pair<PROX>(xa[q], za[q], wa[q], pc); prox_pair<PROX>(xb[q], zb[q], wb[q], pc); }
+        SL_ST4(b.z, soff, za); SL_ST4(b.w, soff, wa);
+        SL_ST4(b.z, soffb, zb); SL_ST4(b.w, soffb, wb);
     }
     if (HAS_INV && last) {
-        st4(b.x, voff, soff, xa);
-        st4(b.x, voff, soffb, xb);
+        SL_ST4(b.x, soff, xa);
+        SL_ST4(b.x, soffb, xb);
     }
+#undef SL_ST4
     if (HAS_FWD) {
-        *reinterpret_cast<float4*>(cell) = make_float4(za[0] - wa[0], zb[0] - wb[0], za[1] - wa[1], zb[1] - wb[1]);
-        *reinterpret_cast<float4*>(cell + 2) = make_float4(za[2] - wa[2], zb[2] - wb[2], za[3] - wa[3], zb[3] - wb[3]);
+        *reinterpret_cast<float4*>(cell) = make_float4(za[0].x - wa[0].x, zb[0].x - wb[0].x, za[0].y - wa[0].y, zb[0].y - wb[0].y);
+        *reinterpret_cast<float4*>(cell + 2) = make_float4(za[1].x - wa[1].x, zb[1].x - wb[1].x, za[1].y - wa[1].y, zb[1].y - wb[1].y);
     }
 }
 
@@ -397,6 +419,13 @@ __device__ __forceinline__ void t_load_rows(c32 (&F)[16], const c32* rp, int t) 
     }
 }
 
+// (d, m) = (C_r[c], C_r[-c]) of a row pair -> the row transforms of its two REAL image rows at column c:
+//   even = unpack_a(d, m) = (d + conj m) / 2,   odd = unpack_b(d, m) = (d - conj m) / (2 i)     (fft16.h), one packed add each
+__device__ __forceinline__ void unpack_both(f2 d, f2 m, f2& even, f2& odd) {
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(even) : "v"(d), "v"(m));                                  // (d.x + m.x, d.y - m.y)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(odd) : "v"(d), "v"(m));      // (d.y + m.y, m.x - d.x)
+}
+
 template <int P>
 __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL_SETS][16], c32* buf, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
@@ -407,13 +436,18 @@ __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL
     for (int h = 0; h < 2; ++h) {                       // the two column-form sets of this pass: 2P and 2P + 1
         const int cc = 32 * h + 4 * wv + g, odd = t & 1;
         const bool packed = (P == 0 && h == 0 && cc == 0);
-        const c32* col = buf + (t >> 1) * SL_P + cc;
+        const f2* col = reinterpret_cast<const f2*>(buf + (t >> 1) * SL_P + cc);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const c32 d = col[8 * j * SL_P], m = col[8 * j * SL_P + SL_M];
-            const c32 va = packed ? mk<float>(d.x, m.x) : unpack_a(d, m);
-            const c32 vb = packed ? mk<float>(d.y, m.y) : unpack_b(d, m);
-            G[2 * P + h][j] = odd ? vb : va;
+            const f2 d = col[8 * j * SL_P], m = col[8 * j * SL_P + SL_M];
+            f2 ve, vo;
+            unpack_both(d, m, ve, vo);
+            f2 v = (odd ? vo : ve) * 0.5f;
+            if (P == 0 && h == 0) {                     // the packed column c = 0 takes the raw values: (C[0], C[128]) -> re / im parts
+                const f2 raw = odd ? k2(d.y, m.y) : k2(d.x, m.x);
+                v = packed ? raw : v;
+            }
+            G[2 * P + h][j] = from2(v);
             pin(G[2 * P + h][j]);                       // unpack as the values arrive: raw pairs must not pile up across the barrier
         }
     }
@@ -430,12 +464,18 @@ __device__ __forceinline__ void t2_pass(const c32 (&G)[SL_SETS][16], c32 (&F)[SL
         c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+            // the lane pair (even, odd) holds (ue, uo) = column values of image rows 2r, 2r + 1; the even lane writes
+            // repack_p(ue, uo) = ue + i uo, the odd lane repack_q(ue, uo) = conj ue + i conj uo.  In terms of the lane's own
+            // value and its partner's:  A = own.x - other.y,  B = own.y + other.x  ->  even (A, B), odd (B, A)
             const c32 own = G[2 * P + h][j];
             const c32 other = dpp_lane_xor1(own);
-            const c32 ue = odd ? other : own, uo = odd ? own : other;
-            const c32 dp = packed ? mk<float>(ue.x, uo.x) : repack_p(ue, uo);
-            const c32 dq = packed ? mk<float>(ue.y, uo.y) : repack_q(ue, uo);
-            col[8 * j * SL_P] = odd ? dq : dp;
+            const float A = own.x - other.y, Bv = own.y + other.x;
+            c32 v = mk<float>(odd ? Bv : A, odd ? A : Bv);
+            if (P == 0 && h == 0) {                     // packed column: (ue.x, uo.x) / (ue.y, uo.y)
+                const c32 raw = mk<float>(odd ? other.y : own.x, odd ? own.y : other.x);
+                v = packed ? raw : v;
+            }
+            col[8 * j * SL_P] = v;
         }
     }
     __syncthreads();
