@@ -59,7 +59,8 @@ struct SliceArgs {
 };
 
 constexpr int WREG = 4 * 272;                 // complex elements of a wave's private LDS region: 4 transform groups x (16 runs of 17)
-constexpr int SL_LDS = SL_BUF + 272;           // transposition buffer (the 8 wave regions alias its start) + W256 table
+constexpr int SL_YS = SL_BUF + 272;            // operands of the packed column's second half (k2 = 128): Ys (256 complex) + Ms (64 words), see col_phase
+constexpr int SL_LDS = SL_YS + 256 + 32;       // transposition buffer (the 8 wave regions alias its start) + W256 table + those
 static_assert(SL_WAVES * WREG <= SL_BUF, "wave regions must fit in the buffer they alias");
 
 // wave-synchronous ordering of LDS traffic: a wave's LDS instructions execute in order, so no
@@ -498,12 +499,20 @@ __device__ __forceinline__ void issue_col_loads(const SliceBufs& b, ColLoads& Y,
     for (int j = 0; j < 16; ++j) Y.yh[j] = ldc(b.yh, 8 * lane, ybase + j * 4096);
 }
 
-__device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G)[SL_SETS][16], c32* wreg, const c32* twl, int wv, int lane) {
+__device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G)[SL_SETS][16], c32* wreg, c32* ysl, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * 272;
     const float ch = 0.5f * cdc;
     ColLoads Y;
     issue_col_loads(b, Y, 0, wv, lane);
+    if (wv == 0) {
+        // wave 0 also owns the packed column's second half.  Its operands (2 KiB + 16 words) go straight to LDS
+        // (`buffer_load ... lds`, no registers) while the first transform runs: fetched inside the branch below they
+        // cost this wave a full memory latency, and the other seven waited for it at the barrier (2.5 us per iteration)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b.ys, ysl, 16, 16 * lane, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b.ys, ysl + 128, 16, 16 * lane, 1024, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b.ms, ysl + 256, 4, 4 * lane, 0, 0, 0);       // lanes 16.. are out of range: zeros
+    }
 #pragma unroll
     for (int set = 0; set < SL_SETS; ++set) {
         c32 (&a)[16] = G[set];
@@ -513,12 +522,12 @@ __device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G
 #pragma unroll
             for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];
             wave_sync();
-            const uint32_t code_b = __builtin_amdgcn_raw_buffer_load_b32(b.ms, 4 * t, 0, 0);
+            const uint32_t code_b = reinterpret_cast<const uint32_t*>(ysl + 256)[t];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const c32 gm = region[(256 - (t + 16 * j)) & 255];
                 const c32 A = blend_one(unpack_a(a[j], gm), Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, ch);
-                const c32 Bv = blend_one(unpack_b(a[j], gm), ldc(b.ys, 8 * t, 128 * j), (int)((code_b >> (2 * j)) & 3u), cdc, ch);
+                const c32 Bv = blend_one(unpack_b(a[j], gm), ysl[t + 16 * j], (int)((code_b >> (2 * j)) & 3u), cdc, ch);
                 a[j] = repack_p(A, Bv);
             }
             wave_sync();
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
             t1_pass<0>(F, G, lds, wv, opaque(lane));
             t1_pass<1>(F, G, lds, wv, opaque(lane));
             if (prof) *prof++ = wall_clock64();
-            col_phase(b, p.c, G, wreg, twl, wv, opaque(lane));
+            col_phase(b, p.c, G, wreg, lds + SL_YS, twl, wv, opaque(lane));
             if (prof) *prof++ = wall_clock64();
             __syncthreads();
             if (prof) *prof++ = wall_clock64();
