@@ -58,8 +58,14 @@ struct SliceArgs {
     long long* prof;          // optional phase clock dump (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
 };
 
-constexpr int WREG = 4 * 272;                 // complex elements of a wave's private LDS region: 4 transform groups x (16 runs of 17)
-constexpr int SL_YS = SL_BUF + 272;            // operands of the packed column's second half (k2 = 128): Ys (256 complex) + Ms (64 words), see col_phase
+// LDS geometry of the transforms.  Rows of RP = 18 complex (144 B): 16-byte aligned, so a lane reads its row by
+// ds_read_b128 (256 B/clk; the ds_read2_b64 hipcc forms from 8-byte reads runs at half that), and conflict-free both
+// ways: a 16-lane group's b128 reads start at banks 36 t mod 64 = sixteen distinct 4-bank groups, its b64 column
+// writes are 16 consecutive values.
+constexpr int RP = 18;
+constexpr int REGION = 16 * RP;               // one transform group's exchange region (also holds a row pair in natural order: 256)
+constexpr int WREG = 4 * REGION;              // complex elements of a wave's private LDS region: 4 transform groups
+constexpr int SL_YS = SL_BUF + REGION;            // operands of the packed column's second half (k2 = 128): Ys (256 complex) + Ms (64 words), see col_phase
 constexpr int SL_LDS = SL_YS + 256 + 32;       // transposition buffer (the 8 wave regions alias its start) + W256 table + those
 static_assert(SL_WAVES * WREG <= SL_BUF, "wave regions must fit in the buffer they alias");
 
@@ -211,9 +217,9 @@ __device__ __forceinline__ void dft16_pk(f2 (&a)[16]) {
 // 16-lane FFT-256 on a[16] (lane t holds index t + 16 j), exchange through the group's region
 template <bool INV>
 __device__ __forceinline__ void group_fft256(c32 (&ac)[16], const c32* twl, c32* region, int t) {
-    // twl is stored per lane in rows of 17: twl[17 t + k] = W256^(t k): one address register + immediate offsets,
-    // and the 16 lanes of a group hit 16 different banks (rows of 16 would be an 8-way conflict)
-    const f2* tw = reinterpret_cast<const f2*>(twl + 17 * t);
+    // twl is stored per lane in rows of RP: twl[RP t + k] = W256^(t k): one address register + immediate offsets
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* tw4 = reinterpret_cast<const f4*>(twl + RP * t);       // (tw[2m], tw[2m + 1]), tw[k] = W256^(t k)
     f2* reg2 = reinterpret_cast<f2*>(region);
     f2 a[16];
 #pragma unroll
@@ -221,15 +227,28 @@ __device__ __forceinline__ void group_fft256(c32 (&ac)[16], const c32* twl, c32*
     dft16_pk<INV>(a);
     mem_fence_compiler();                          // twiddles fetched after the butterflies (not piled up in registers before them)
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = tmul_v<INV>(a[k], tw[k]);
+    for (int m = 0; m < 4; ++m) {
+        const f4 q = tw4[m];
+        if (m) a[2 * m] = tmul_v<INV>(a[2 * m], k2(q.x, q.y));
+        a[2 * m + 1] = tmul_v<INV>(a[2 * m + 1], k2(q.z, q.w));
+    }
     mem_fence_compiler();
 #pragma unroll
-    for (int k = 8; k < 16; ++k) a[k] = tmul_v<INV>(a[k], tw[k]);
+    for (int m = 4; m < 8; ++m) {
+        const f4 q = tw4[m];
+        a[2 * m] = tmul_v<INV>(a[2 * m], k2(q.x, q.y));
+        a[2 * m + 1] = tmul_v<INV>(a[2 * m + 1], k2(q.z, q.w));
+    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) reg2[k * 17 + t] = a[k];
+    for (int k = 0; k < 16; ++k) reg2[k * RP + t] = a[k];
     wave_sync();
+    const f4* row4 = reinterpret_cast<const f4*>(reg2 + t * RP);
 #pragma unroll
-    for (int n = 0; n < 16; ++n) a[n] = reg2[t * 17 + n];
+    for (int m = 0; m < 8; ++m) {
+        const f4 q = row4[m];
+        a[2 * m] = k2(q.x, q.y);
+        a[2 * m + 1] = k2(q.z, q.w);
+    }
     wave_sync();
     dft16_pk<INV>(a);
 #pragma unroll
@@ -347,7 +366,7 @@ template <bool HAS_INV, int PROX, bool HAS_FWD>
 __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32 (&F)[SL_SETS][16],
                                           c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
-    c32* region = wreg + g * 272;
+    c32* region = wreg + g * REGION;
     // PF row pairs of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
     constexpr int PF = (PROX == 3) ? 4 : SLICE_PF;
     RowLoads L;
@@ -368,7 +387,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int soff = (2 * (32 * set + 4 * wv + i)) * 1024;
-            pointwise_rowpair<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, wreg + i * 272 + 4 * lane, 16 * lane, soff,
+            pointwise_rowpair<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, wreg + i * REGION + 4 * lane, 16 * lane, soff,
                                                                L.za[i], L.wa[i], L.zb[i], L.wb[i]);
         }
         if (set + 1 < SL_SETS) issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, set + 1, wv, lane);
@@ -420,13 +439,12 @@ __device__ __forceinline__ void t_load_rows(c32 (&F)[16], const c32* rp, int t) 
     }
 }
 
-// (d, m) = (C_r[c], C_r[-c]) of a row pair -> the row transforms of its two REAL image rows at column c:
-//   even = unpack_a(d, m) = (d + conj m) / 2,   odd = unpack_b(d, m) = (d - conj m) / (2 i)     (fft16.h), one packed add each
-__device__ __forceinline__ void unpack_both(f2 d, f2 m, f2& even, f2& odd) {
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(even) : "v"(d), "v"(m));                                  // (d.x + m.x, d.y - m.y)
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(odd) : "v"(d), "v"(m));      // (d.y + m.y, m.x - d.x)
-}
-
+// T1 read side.  (d, m) = (C_r[c], C_r[-c]) of a row pair give the row transforms of its two REAL image rows at column c:
+//   even lane: unpack_a(d, m) = (d + conj m) / 2,   odd lane: unpack_b(d, m) = (d - conj m) / (2 i)     (fft16.h).
+// The even lane of a pair reads d, the odd lane m -- ONE 8-byte LDS read per lane and value (a lane reading both makes
+// hipcc emit ds_read2_b64, which moves 16 bytes per lane at half the LDS rate) -- and the partner's value comes by DPP:
+//   own = (even ? d : m), other = partner's own;   p = odd ? own.y : own.x,  q = odd ? own.x : own.y
+//   value = ( p + partner's q,  q - partner's p ) / 2      -- the sums and differences of unpack_a / unpack_b, term for term
 template <int P>
 __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL_SETS][16], c32* buf, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
@@ -437,19 +455,19 @@ __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL
     for (int h = 0; h < 2; ++h) {                       // the two column-form sets of this pass: 2P and 2P + 1
         const int cc = 32 * h + 4 * wv + g, odd = t & 1;
         const bool packed = (P == 0 && h == 0 && cc == 0);
-        const f2* col = reinterpret_cast<const f2*>(buf + (t >> 1) * SL_P + cc);
+        const c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const f2 d = col[8 * j * SL_P], m = col[8 * j * SL_P + SL_M];
-            f2 ve, vo;
-            unpack_both(d, m, ve, vo);
-            f2 v = (odd ? vo : ve) * 0.5f;
+            const c32 own = col[8 * j * SL_P];
+            const float pp = odd ? own.y : own.x, qq = odd ? own.x : own.y;
+            const float dq = dpp_lane_xor1(qq), dp = dpp_lane_xor1(pp);
+            c32 v = mk<float>(0.5f * (pp + dq), 0.5f * (qq - dp));
             if (P == 0 && h == 0) {                     // the packed column c = 0 takes the raw values: (C[0], C[128]) -> re / im parts
-                const f2 raw = odd ? k2(d.y, m.y) : k2(d.x, m.x);
+                const c32 raw = mk<float>(odd ? dq : pp, odd ? pp : dq);
                 v = packed ? raw : v;
             }
-            G[2 * P + h][j] = from2(v);
-            pin(G[2 * P + h][j]);                       // unpack as the values arrive: raw pairs must not pile up across the barrier
+            G[2 * P + h][j] = v;
+            pin(G[2 * P + h][j]);                       // unpack as the values arrive: raw values must not pile up across the barrier
         }
     }
     __syncthreads();
@@ -501,7 +519,7 @@ __device__ __forceinline__ void issue_col_loads(const SliceBufs& b, ColLoads& Y,
 
 __device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G)[SL_SETS][16], c32* wreg, c32* ysl, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
-    c32* region = wreg + g * 272;
+    c32* region = wreg + g * REGION;
     const float ch = 0.5f * cdc;
     ColLoads Y;
     issue_col_loads(b, Y, 0, wv, lane);
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index as a scalar: bases below stay in SGPRs
     c32* twl = lds + SL_BUF;
-    if (tid < 256) twl[17 * (tid >> 4) + (tid & 15)] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k), rows of 17: bank-conflict free
+    if (tid < 256) twl[RP * (tid >> 4) + (tid & 15)] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k), rows of RP
     c32* wreg = lds + wv * WREG;
     if (p.stagger_ticks > 0) {
         // experiment knob (PNP_SLICE_STAGGER_US, default off): equal workgroups started together run their HBM-heavy
