@@ -174,9 +174,9 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
             c->fused = fused256_create(Bmax, &fe);
             // Slice-resident loops: one workgroup (= one compute unit) per slice, so they pay off once the batch
             // fills the chip; small batches stay on the two-launch path, which spreads a slice over many CUs.
-            // PNP_SLICE=0 never, =1 always, unset: batches that occupy enough of the chip's compute units (slice_pays()).
+            // PNP_SLICE=0 never, =1 always, unset: batches of at least PNP_SLICE_MIN_B slices (slice_pays()).
             const int mode = env_int("PNP_SLICE", -1);
-            c->slice_min_b = mode == 1 ? 1 : env_int("PNP_SLICE_MIN_B", 112);
+            c->slice_min_b = mode == 1 ? 1 : env_int("PNP_SLICE_MIN_B", 64);
             c->slice_force = (mode == 1);
             if (c->fused && mode != 0 && Bmax >= c->slice_min_b) {
                 c->slice = slice256_create(Bmax, &fe);
@@ -280,15 +280,12 @@ static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_i
 
 // One workgroup per slice, one workgroup per compute unit at a time: the batch runs in rounds of `cus` slices.
 // Measured on MI355X, ms per iteration, two-launch vs slice-resident (profiles/run_slice_sizes.sh, one box):
-//   B = 96: 0.046 / 0.047   128: 0.055 / 0.049   192: 0.074 / 0.057   256: 0.097 / 0.065   288: 0.112 / 0.110
-//   320: 0.124 / 0.112   384: 0.145 / 0.114   512: 0.198 / 0.124   768: 0.345 / 0.179
-// so: at least PNP_SLICE_MIN_B (112) slices, and no nearly empty last round (a round costs the same full or not).
+//   B = 64: 0.0370 / 0.0369   80: 0.0410 / 0.0378   96: 0.0448 / 0.0382   128: 0.0544 / 0.0405   256: 0.0954 / 0.0565
+//   272: 0.1063 / 0.0904   320: 0.1224 / 0.0936   512: 0.1919 / 0.1075   640: 0.2506 / 0.1445
+// A round costs the same full or not, and even a nearly empty second round (B = 272) beats the two-launch path:
+// the rule is simply "at least PNP_SLICE_MIN_B (64) slices".
 static bool slice_pays(pnp_ctx* c) {
-    if (c->slice_force) return true;
-    if (c->B < c->slice_min_b) return false;
-    const int cus = slice256_cus(c->slice);
-    const int rest = c->B % cus;
-    return rest == 0 || 100 * rest >= 15 * cus;
+    return c->slice_force || c->B >= c->slice_min_b;
 }
 
 static int prepare_fused(pnp_ctx* c) {

@@ -75,17 +75,17 @@ def test_slice_resident_equals_two_launch_path_state(P, golden_inputs, monkeypat
 
 
 def test_path_selection_by_batch_size(P, monkeypatch):
-    """Which loops run slice-resident (pnp_path_name): batches of at least 112 slices unless their last round of
-    256 (one workgroup per compute unit) would be nearly empty; PNP_SLICE=0 / 1 override."""
+    """Which loops run slice-resident (pnp_path_name): batches of at least 64 slices (PNP_SLICE_MIN_B); PNP_SLICE=0 / 1
+    override."""
     monkeypatch.delenv('PNP_SLICE', raising=False)
     mask = np.ones((256, 256), np.uint8)
     with P.Engine(256, 256, Bmax=520) as eng:
-        for B, want in ((64, 'fused'), (111, 'fused'), (112, 'slice'), (131, 'slice'), (256, 'slice'), (288, 'fused'),
-                        (320, 'slice'), (512, 'slice'), (520, 'fused')):
+        for B, want in ((6, 'fused'), (63, 'fused'), (64, 'slice'), (131, 'slice'), (256, 'slice'), (288, 'slice'),
+                        (512, 'slice'), (520, 'slice')):
             eng.upload(np.zeros((B, 256, 256), np.complex64), mask)
             assert eng.path_name == want, (B, eng.path_name)
-    with P.Engine(256, 256, Bmax=64) as eng:             # a context that can never hold a slice-resident batch has no tables
-        eng.upload(np.zeros((64, 256, 256), np.complex64), mask)
+    with P.Engine(256, 256, Bmax=48) as eng:             # a context that can never hold a slice-resident batch has no tables
+        eng.upload(np.zeros((48, 256, 256), np.complex64), mask)
         assert eng.path_name == 'fused'
     monkeypatch.setenv('PNP_SLICE', '0')
     with P.Engine(256, 256, Bmax=512) as eng:
