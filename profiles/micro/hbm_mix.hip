@@ -1,7 +1,9 @@
 // Calibration, not product: what does this GPU sustain on the slice-resident kernel's traffic MIX with a trivial
 // streaming kernel?  Per "iteration": read z, w (2 x 128 MiB), read a 128 MiB operand table, write z, w in place --
 // the same 3 reads : 2 writes over the same 384 MiB working set (larger than the 256 MiB MALL) as one ADMM iteration
-// at batch 512.  Also pure read, pure write and copy for reference.   hipcc -O3 --offload-arch=gfx950 hbm_mix.hip -o hbm_mix
+// at batch 512.  Also pure read, pure write and copy for reference.  argv[1] = MiB per array (default 128): 64 MiB x 3 is the
+// slice-resident kernel's live working set (256 slices in flight), inside the 256 MiB MALL.
+//   hipcc -O3 --offload-arch=gfx950 hbm_mix.hip -o hbm_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,12 +19,12 @@ __global__ __launch_bounds__(256) void k_mix(float4* z, float4* w, const float4*
 // the same with four independent float4 triples in flight per thread (more bytes in flight per wave)
 __global__ __launch_bounds__(256) void k_mix4(float4* z, float4* w, const float4* y, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
         float4 a[4], b[4], c[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = z[i + u * stride]; b[u] = w[i + u * stride]; c[u] = y[i + u * stride]; }
+        for (int u = 0; u < 4; ++u) if (i + u * stride < n) { a[u] = z[i + u * stride]; b[u] = w[i + u * stride]; c[u] = y[i + u * stride]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4; ++u) if (i + u * stride < n) {
             z[i + u * stride] = make_float4(a[u].x + c[u].x * 1e-9f, a[u].y + c[u].y * 1e-9f, a[u].z + c[u].z * 1e-9f, a[u].w + c[u].w * 1e-9f);
             w[i + u * stride] = make_float4(b[u].x - c[u].x * 1e-9f, b[u].y - c[u].y * 1e-9f, b[u].z - c[u].z * 1e-9f, b[u].w - c[u].w * 1e-9f);
         }
