@@ -94,15 +94,25 @@ int main(int argc, char** argv) {
             if (mine != 8) return 7;                                              // every thread moves 8 values per set and pass
         }
         if (written != 128 * 128) return 7;
+        // the kernel's lane-level form (t1_pass): the even lane of a pair reads C[c], the odd lane C[-c]; the partner's
+        // value arrives by DPP; p / q pick the components so that one add and one subtract serve both parities
         for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 2 * p; set < 2 * p + 2; ++set) {
-            const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63;
+            const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63, odd = t & 1;
             for (int j = 0; j < 16; ++j) {
                 const int rho = t + 16 * j, r = rho >> 1;
                 const C d = LDS[r * SL_P + cc], m = LDS[r * SL_P + SL_M + cc];
                 if (std::isnan(d.x) || std::isnan(m.x)) return 8;
-                C v;
-                if (c == 0) v = (rho & 1) ? mk<R>(d.y, m.y) : mk<R>(d.x, m.x);
-                else        v = (rho & 1) ? unpack_b(d, m) : unpack_a(d, m);
+                const C own = odd ? m : d, other = odd ? d : m;                    // other = what the partner lane read
+                const R pp = odd ? own.y : own.x, qq = odd ? own.x : own.y;
+                const R pp_partner = odd ? other.x : other.y, qq_partner = odd ? other.y : other.x;   // the partner has the opposite parity
+                C v = mk<R>((R)0.5 * (pp + qq_partner), (R)0.5 * (qq - pp_partner));
+                const C ref = (rho & 1) ? unpack_b(d, m) : unpack_a(d, m);
+                if (v.x != ref.x || v.y != ref.y) return 12;                       // bit-equal to unpack_a / unpack_b
+                if (c == 0) {
+                    v = odd ? mk<R>(qq_partner, pp) : mk<R>(pp, qq_partner);
+                    const C raw = (rho & 1) ? mk<R>(d.y, m.y) : mk<R>(d.x, m.x);
+                    if (v.x != raw.x || v.y != raw.y) return 13;
+                }
                 G[wv][lane][set][j] = v;
             }
         }
@@ -135,13 +145,20 @@ int main(int argc, char** argv) {
     // ---- T2: column form -> row form -------------------------------------------------------------
     for (int p = 0; p < 2; ++p) {
         for (int i = 0; i < SL_BUF; ++i) LDS[i] = mk<R>(NAN, NAN);
-        for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; lane += 2) for (int set = 2 * p; set < 2 * p + 2; ++set) {
-            const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63;                // t even; lane + 1 is its partner
+        // the kernel's lane-level form (t2_pass): A = own.x - other.y, B = own.y + other.x; the even lane writes (A, B) to the
+        // direct slot, the odd lane (B, A) to the mirror slot
+        for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 2 * p; set < 2 * p + 2; ++set) {
+            const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63, odd = t & 1;
             for (int j = 0; j < 16; ++j) {
                 const int r = (t + 16 * j) >> 1;
-                const C ue = F[wv][lane][set][j], uo = F[wv][lane + 1][set][j];
-                LDS[r * SL_P + cc]        = (c == 0) ? mk<R>(ue.x, uo.x) : repack_p(ue, uo);    // written by the even lane
-                LDS[r * SL_P + SL_M + cc] = (c == 0) ? mk<R>(ue.y, uo.y) : repack_q(ue, uo);    // written by the odd lane
+                const C own = F[wv][lane][set][j], other = F[wv][lane ^ 1][set][j];
+                const R A = own.x - other.y, Bv = own.y + other.x;
+                C v = odd ? mk<R>(Bv, A) : mk<R>(A, Bv);
+                const C ue = odd ? other : own, uo = odd ? own : other;
+                const C ref = odd ? repack_q(ue, uo) : repack_p(ue, uo);
+                if (v.x != ref.x || v.y != ref.y) return 14;                       // bit-equal to repack_p / repack_q
+                if (c == 0) v = odd ? mk<R>(other.y, own.y) : mk<R>(own.x, other.x);                  // = (ue.x, uo.x) / (ue.y, uo.y)
+                LDS[r * SL_P + (odd ? SL_M : 0) + cc] = v;
             }
         }
         for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
