@@ -230,7 +230,7 @@ int pnp_get_schedule(pnp_ctx* c, int* queues, int* mixed_launches, int* chunk) {
 }
 int pnp_set_schedule(pnp_ctx* c, int queues, int mixed_launches, int chunk) {
     CTX(c);
-    if (queues < 1 || queues > 4 || chunk < 0) return fail(PNP_E_ARG, "pnp_set_schedule: queues in 1..4, chunk >= 0");
+    if (queues < 1 || queues > 4) return fail(PNP_E_ARG, "pnp_set_schedule: queues in 1..4");
     c->sched.queues = queues; c->sched.mixed = mixed_launches != 0; c->sched.chunk = chunk;
     return PNP_OK;
 }
@@ -717,7 +717,10 @@ int pnp_kernels_per_iteration(pnp_ctx* c) {
     if (!c) return 0;
     if (!use_fused(c)) return 3;                      // generic: rows, columns, rows
     if (c->slice && c->slice_ready) return 0;         // one launch per RUN: the iterations are a loop inside it
-    if (c->fs32 || c->fs64) return (c->sched.queues >= 2 && c->B >= 64 && c->sched.chunk <= 0) ? 4 : 2;
+    if (c->fs32 || c->fs64) {
+        const int chunk = c->sched.chunk != 0 ? c->sched.chunk : (c->fs64 ? 96 : 0);     // fused256s_run's default
+        return (c->sched.queues >= 2 && c->B >= 64 && chunk <= 0) ? 4 : 2;
+    }
     const int q = (c->fused5 || c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
     return 2 * q;                                     // two launches per queue and batched iteration
 }

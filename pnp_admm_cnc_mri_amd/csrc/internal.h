@@ -75,7 +75,8 @@ hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double*
 struct FusedSchedule {
     int queues = 2;         // HIP queues the batch is split over (1..4); kernel heads/tails overlap
     int mixed = 0;          // 256x256: row workgroups of one half + column workgroups of the other per launch (k_fmixed)
-    int chunk = 0;          // >0: finish all iterations on `chunk` slices before the next chunk (single queue)
+    int chunk = 0;          // >0: finish all iterations on `chunk` slices before the next chunk (single queue); 0: the path's default
+                            // (512x512: 48, double 256x256: 96, float 256x256: off); <0: off
     int l1_two_state = 0;   // test hook: ADMM_L1 keeps z and w every iteration instead of u only
 };
 

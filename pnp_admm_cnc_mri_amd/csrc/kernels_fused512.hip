@@ -366,7 +366,18 @@ hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x
     // 0.49 ms against 0.451 ms per iteration at 256 slices -- the 240-VGPR column body would drag
     // the row body down to 2 waves/SIMD in a mixed launch), so the queue / mixed knobs of
     // FusedSchedule apply to the 256x256 path only.
-    return run5_chunk(f, s, z, w, x, 0, B, iters, prox, dc_c, pp);
+    // All iterations on `chunk` slices before the next chunk: 4 MiB per slice (z, w, T, Yh), so 48 slices keep a chunk's
+    // whole working set inside the 256 MiB Infinity Cache for the run.  Measured at 256 slices, 100 CNC iterations, one box,
+    // 4 alternating repetitions: 48 -> 1161-1162 it/s, 128 -> 1155-1159, whole batch -> 1057-1060 on that box (the whole
+    // batch runs 1165 on other boxes and runs: a slow mode the chunks avoid); 32 -> 1008.  sch.chunk (PNP_FUSED_CHUNK)
+    // overrides; < 0 = whole batch.
+    const int chunk_req = sch.chunk != 0 ? sch.chunk : 48;
+    int chunk = chunk_req > 0 ? (chunk_req & ~1) : B;
+    if (chunk < 2) chunk = 2;
+    hipError_t e = hipSuccess;
+    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
+        e = run5_chunk(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
+    return e;
 }
 
 hipError_t fused512_dc(Fused512* f, hipStream_t s, const float* z, const float* w, float* x, int B, float dc_c) {

@@ -378,3 +378,39 @@ def test_config4_shard_full_batch_drunet(env):
         return den(t, i)[0, 0].cpu().numpy()
     ref = O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), mask, denoise, 1, 1, 0.8, 0.8, 0.45)
     assert rel_l2(full[B - 1], ref) <= 1e-5, rel_l2(full[B - 1], ref)
+
+
+# ----------------------------------------------------------------------------------------------
+# chunked schedules (defaults of the 512x512 and of the double-precision 256x256 loops)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('H,precision,B,iters', [(512, 'f32', 52, 4), (256, 'f64', 100, 4)])
+def test_chunked_default_schedules_are_bit_identical(env, H, precision, B, iters):
+    """512x512 loops run all iterations on 48 slices before the next 48, the double 256x256 engine on 96 (a chunk's working
+    set stays in the Infinity Cache): pure scheduling -- the same bits as the whole batch at once (chunk < 0) and as any
+    other chunk size, for x and for the state."""
+    P = env['P']
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    masks = np.stack([S.synthetic_mask(k, H, H) for k in ('random', 'radial', 'cartesian')]).astype(np.uint8)
+    img, noise = S.batch(0, B, H, H)
+    mid = np.arange(B) % 3
+    with P.Engine(H, H, Bmax=B) as e32:                      # measurements from the float engine (the double one has no synthesis)
+        e32.synthesize(img, noise, masks, mid)
+        y = e32.download_y()
+    res = []
+    with P.Engine(H, H, Bmax=B, precision=precision) as eng:
+        for chunk in (0, -1, 10):
+            eng.set_schedule(queues=2, mixed_launches=True, chunk=chunk)
+            assert eng.schedule['chunk'] == chunk
+            eng.upload(y, masks, mid)
+            assert eng.path_name == 'fused'
+            eng.init_state()
+            eng.admm_cnc(iters, 0.45, 0.5, 0.05, 64)
+            x = eng.x()
+            z, w = eng.get_state()
+            eng.init_state()
+            eng.admm_l1(iters, 0.1, 0.015)
+            res.append((x, z, w, eng.x()))
+    assert np.isfinite(res[0][0]).all()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
