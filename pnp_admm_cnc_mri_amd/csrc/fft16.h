@@ -256,7 +256,20 @@ struct ProxCoefT {
 };
 using ProxCoef = ProxCoefT<float>;
 
+// clamp(a, -c, c), c >= 0; one v_med3_f32 in float device code
+template <typename R> PNP_HD R clamp_sym(R a, R c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (same_type<R, float>::value) return __builtin_amdgcn_fmed3f(a, -c, c);
+#endif
+    return a < -c ? -c : (a > c ? c : a);
+}
+// soft(a, c) = max(|a| - c, 0) sign(a) (S1:18-19).  Float device code computes it as a - clamp(a, -c, c): the same value bit
+// for bit (|a| <= c: a - a = 0; beyond: the very same subtraction), a zero's sign aside (tests/test_kernel_identities.py) --
+// two instructions instead of a compare / select chain.
 template <typename R> PNP_HD R soft_thr(R a, R c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (same_type<R, float>::value) return a - clamp_sym(a, c);
+#endif
     const R m = (a < 0 ? -a : a) - c;
     const R r = m > 0 ? m : (R)0;
     return a < 0 ? -r : r;
@@ -268,7 +281,7 @@ template <typename R> PNP_HD void prox_l1_pt(R x, R& z, R& w, const ProxCoefT<R>
 }
 template <typename R> PNP_HD void prox_cnc_pt(R x, R& z, R& w, const ProxCoefT<R>& p) {
     const R u = x + w;
-    const R cz = z < -p.ib ? -p.ib : (z > p.ib ? p.ib : z);   // z - soft(z, 1/b)
+    const R cz = clamp_sym(z, p.ib);                           // z - soft(z, 1/b)
     const R t = fma_(p.c1, z, fma_(p.c2, u, p.c3 * cz));
     z = soft_thr(t, p.thr);
     w = u - z;
