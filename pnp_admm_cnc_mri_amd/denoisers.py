@@ -237,7 +237,7 @@ class Denoiser:
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
 
     def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
-                 cnn_batch=64, channels_last=True, cnn_dtype=None):
+                 cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto'):
         self.name, self.fam = model_name, family(model_name)
         self.model = model
         self.noise_level_model = noise_level_model
@@ -247,6 +247,12 @@ class Denoiser:
         self.former_idx = 0
         self.cnn_batch = cnn_batch
         self.channels_last = channels_last        # NHWC weights/activations: MIOpen's faster fp32 conv path (+9 %)
+        # MIOpen "find" mode (torch.backends.cudnn.benchmark) for the forward passes.  Without a find-db entry MIOpen's
+        # immediate mode can fall back to a kernel that is two orders of magnitude slower: on a fresh MI355X box the
+        # FFDNet stack at 64 x 1 x 256 x 256 per call ran 25.7 s per PnP iteration (512 slices) against 0.172 s once a
+        # find had run.  'auto' = find for conv batches of at least 16 images (throughput runs; one-off search of a few
+        # seconds per new shape, cached by MIOpen), immediate mode for the single-image calls of the reference-sized runs.
+        self.miopen_find = miopen_find
         # None = float32 (parity with the reference).  'bf16' / 'fp16' run the conv stack under
         # torch.autocast on the MFMA low-precision path: a throughput mode that does NOT meet the
         # 1e-5 parity bar and is never used by tests of record.
@@ -307,10 +313,17 @@ class Denoiser:
         B = x.shape[0]
         if out is None:
             out = torch.empty_like(x)
-        for b0 in range(0, B, self.cnn_batch):
-            if self.cnn_dtype is None:
-                out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)
-            else:
-                with torch.autocast('cuda', dtype=self.cnn_dtype):
-                    out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i).float()
+        find = (min(B, self.cnn_batch) >= 16 and x.is_cuda) if self.miopen_find == 'auto' else bool(self.miopen_find)
+        cd = torch.backends.cudnn
+        before = cd.benchmark
+        cd.benchmark = bool(find or before)
+        try:
+            for b0 in range(0, B, self.cnn_batch):
+                if self.cnn_dtype is None:
+                    out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)
+                else:
+                    with torch.autocast('cuda', dtype=self.cnn_dtype):
+                        out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i).float()
+        finally:
+            cd.benchmark = before
         return out
