@@ -350,15 +350,15 @@ def test_split_chain_float_engine_vs_oracle(env, golden_inputs, solver, monkeypa
         assert rel_l2(x[b], ref) <= 2e-6, (b, rel_l2(x[b], ref))
 
 
-@pytest.mark.skipif(os.environ.get('PNP_RUN_SLOW') != '1',
-                    reason='10 minutes on a fresh box: MIOpen compiles DRUNet\'s batch-64 convolutions first (612 s measured, '
-                           'the test itself ~15 s); run with PNP_RUN_SLOW=1.  bench_pnp.py exercises the same shard.')
-def test_config4_shard_full_batch_drunet(env):
+@pytest.mark.skipif(os.environ.get('PNP_SKIP_SLOW') == '1',
+                    reason='about 2 minutes on a fresh box (MIOpen searches DRUNet\'s batch-64 convolutions once); PNP_SKIP_SLOW=1 skips it')
+def test_config4_shard_full_batch_drunet(env, monkeypatch):
     """Config 4's per-GPU shard at full size: PNP_ADMM_CNC_D with DRUNet on 512 slices of 256x256, Q_Cartesian30,
     S6:577 preset, ONE iteration (two DRUNet forwards over the whole shard).  (a) the 64 slices of one CNN batch
     run alone are bit-equal to the same slices inside the shard; (b) oracle-loop spot check on the last slice."""
     torch, D, S = env['torch'], env['D'], env['S']
     from pnp_admm_cnc_mri_amd import synthetic as SY, utils_pnp
+    monkeypatch.setattr(torch.backends.cudnn, 'deterministic', False)           # as in test_config3_full_batch_properties
     B = 512
     mask = SY.reference_masks()['Q_Cartesian30'].astype(np.uint8)
     with env['P'].Engine(256, 256, Bmax=B) as eng:
