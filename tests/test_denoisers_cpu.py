@@ -127,3 +127,27 @@ def test_augment_modes_match_the_reference(pnp_golden):
     a = torch.arange(2 * 1 * 5 * 7, dtype=torch.float32).reshape(2, 1, 5, 7)
     for m in range(8):
         assert np.array_equal(D.augment_img_tensor4(a, m).numpy(), arrays['augment_mode%d' % m]), m
+
+
+def test_denoiser_call_restores_the_cudnn_benchmark_flag():
+    """Denoiser.__call__ may switch MIOpen's find mode on around its forward passes (miopen_find); the process-wide flag must
+    come back as it was, whatever the setting and also when the forward raises."""
+    import torch
+    from pnp_admm_cnc_mri_amd import denoisers as D
+    net, nlm, _ = D.build('ffdnet_gray')
+    net.load_state_dict(D.seeded_state_dict(net, 3))
+    x = torch.rand(2, 1, 32, 32)
+    for before in (False, True):
+        torch.backends.cudnn.benchmark = before
+        for mode in ('auto', True, False):
+            den = D.Denoiser('ffdnet_gray', net.eval(), nlm, miopen_find=mode)
+            y = den(x, 0)
+            assert y.shape == x.shape and torch.backends.cudnn.benchmark is before
+
+        class Boom(D.Denoiser):
+            def _one(self, x, i):
+                raise RuntimeError('boom')
+        with pytest.raises(RuntimeError):
+            Boom('ffdnet_gray', net.eval(), nlm, miopen_find=True)(x, 0)
+        assert torch.backends.cudnn.benchmark is before
+    torch.backends.cudnn.benchmark = False
