@@ -60,9 +60,10 @@ int pnp_set_fast_path(pnp_ctx* ctx, int enable);
  *   queues          1..4 HIP queues the batch is split over (default 2; forked/joined on the ctx stream)
  *   mixed_launches  256x256: row workgroups of one half of a part share each launch with the column
  *                   workgroups of its other half (default 1)
- *   chunk           >0: run all iterations on `chunk` slices before the next chunk, one queue; 0 (default): the path's own
- *                   default -- 48 slices at 512x512, 96 for the double-precision 256x256 engine (a chunk's working set then
- *                   stays in the 256 MiB Infinity Cache for the whole run), whole batch otherwise; <0: whole batch
+ *   chunk           >0: a queue runs all iterations on `chunk` slices before its next chunk; 0 (default): the path's own
+ *                   default -- at 512x512 and for the double-precision 256x256 engine the chunks go round-robin to 4 queues
+ *                   (16 resp. 24 slices each with queues >= 2; 48 resp. 96 on one queue), so the chunks in flight fit the
+ *                   256 MiB Infinity Cache for a whole run; whole batch otherwise; <0: whole batch
  * Environment defaults read at pnp_ctx_create: PNP_FUSED_STREAMS, PNP_FUSED_SCHED, PNP_FUSED_CHUNK. */
 int pnp_set_schedule(pnp_ctx* ctx, int queues, int mixed_launches, int chunk);
 /* the schedule in force (any pointer may be NULL) */

@@ -717,11 +717,11 @@ int pnp_kernels_per_iteration(pnp_ctx* c) {
     if (!c) return 0;
     if (!use_fused(c)) return 3;                      // generic: rows, columns, rows
     if (c->slice && c->slice_ready) return 0;         // one launch per RUN: the iterations are a loop inside it
-    if (c->fs32 || c->fs64) {
-        const int chunk = c->sched.chunk != 0 ? c->sched.chunk : (c->fs64 ? 96 : 0);     // fused256s_run's default
-        return (c->sched.queues >= 2 && c->B >= 64 && chunk <= 0) ? 4 : 2;
+    if (c->fs32 || c->fs64 || c->fused5) {               // chunked round-robin schedules: two launches per chunk
+        const char* ev = getenv(c->fused5 ? "PNP_F512_QUEUES" : "PNP_F256S_QUEUES");
+        return chunk_plan_launches(c->B, chunk_plan(c->B, c->sched, c->fused5 != nullptr, c->fs64 != nullptr, ev ? atoi(ev) : 0));
     }
-    const int q = (c->fused5 || c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
+    const int q = (c->sched.chunk > 0 || c->sched.queues < 2 || c->B < 32 * c->sched.queues) ? 1 : c->sched.queues;
     return 2 * q;                                     // two launches per queue and batched iteration
 }
 const char* pnp_path_name(pnp_ctx* c) {

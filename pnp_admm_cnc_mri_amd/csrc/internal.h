@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace pnp {
 
@@ -75,10 +76,37 @@ hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double*
 struct FusedSchedule {
     int queues = 2;         // HIP queues the batch is split over (1..4); kernel heads/tails overlap
     int mixed = 0;          // 256x256: row workgroups of one half + column workgroups of the other per launch (k_fmixed)
-    int chunk = 0;          // >0: finish all iterations on `chunk` slices before the next chunk (single queue); 0: the path's default
-                            // (512x512: 48, double 256x256: 96, float 256x256: off); <0: off
+    int chunk = 0;          // >0: a queue finishes all iterations on `chunk` slices before its next chunk; 0: the path's default
+                            // (chunk_plan below); <0: off (whole batch / two halves)
     int l1_two_state = 0;   // test hook: ADMM_L1 keeps z and w every iteration instead of u only
 };
+
+// Chunked schedules of the 512x512 loops and of the split-chain (double) 256x256 loops: a queue runs ALL iterations of a run on
+// `chunk` slices before its next chunk, and the chunks go round-robin to Q queues -- Q chunks in flight, whose working set
+// (Q * chunk * 4 MiB at 512x512, * 2.5 MiB in double) stays around the 256 MiB Infinity Cache and whose kernel tails overlap
+// each other's heads.  Measured on one box each (it/s; profiles/bench_r02):
+//   512x512, 256 slices: whole batch 1057-1171 (a slow mode on some boxes), 1 x 48: 1161-1172, 2 x 32: 1338, 3 x 24: 1360,
+//                        4 x 16: 1358, 4 x 24: 1361, 4 x 8: 1244
+//   double, 512 slices:  two halves on two queues 2186-2400, 1 x 96: 2423, 2 x 48: 2563, 3 x 32: 2570, 4 x 24: 2573, 4 x 64: 2436
+struct ChunkPlan {
+    int queues, chunk;      // chunk == B and queues == 1: the whole batch at once
+};
+static inline ChunkPlan chunk_plan(int B, const FusedSchedule& sch, bool is512, bool is_double, int env_queues /* <=0: none */) {
+    ChunkPlan p;
+    p.queues = env_queues > 0 ? env_queues : (sch.queues >= 2 ? 4 : 1);
+    if (p.queues > 4) p.queues = 4;
+    const int dflt = is512 ? (p.queues >= 2 ? 16 : 48) : (is_double ? (p.queues >= 2 ? 24 : 96) : 0);
+    p.chunk = sch.chunk != 0 ? sch.chunk : dflt;
+    if (p.chunk <= 0) {                                     // off
+        if (!is512 && sch.queues >= 2 && B >= 64) { p.queues = 2; p.chunk = ((B / 2) + 1) & ~1; }     // two halves (round 1)
+        else { p.queues = 1; p.chunk = B; }
+    }
+    p.chunk &= ~1;
+    if (p.chunk < 2) p.chunk = 2;
+    if (p.chunk >= B) { p.chunk = B > 2 ? ((B + 1) & ~1) : 2; p.queues = 1; }
+    return p;
+}
+static inline int chunk_plan_launches(int B, const ChunkPlan& p) { return 2 * ((B + p.chunk - 1) / p.chunk); }
 
 // fused 256x256 path (kernels_fused256.hip): state resident in the ctx, two slices packed into
 // one complex transform.  See DESIGN.md.

@@ -630,8 +630,9 @@ struct Fused256S {
     cxT<R>* T = nullptr;
     cxT<R>* Yh = nullptr;
     uint32_t* Mh = nullptr;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static constexpr int MAXQ2 = 4;
+    hipStream_t side[MAXQ2] = {};             // further queues; [0] unused
+    hipEvent_t ev_fork = nullptr, ev_join[MAXQ2] = {};
 };
 
 template <typename R>
@@ -640,9 +641,11 @@ void fused256s_destroy(Fused256S<R>* f) {
     if (f->T) (void)hipFree(f->T);
     if (f->Yh) (void)hipFree(f->Yh);
     if (f->Mh) (void)hipFree(f->Mh);
-    if (f->side) (void)hipStreamDestroy(f->side);
+    for (int q = 1; q < Fused256S<R>::MAXQ2; ++q) {
+        if (f->side[q]) (void)hipStreamDestroy(f->side[q]);
+        if (f->ev_join[q]) (void)hipEventDestroy(f->ev_join[q]);
+    }
     if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
-    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
     delete f;
 }
 
@@ -735,34 +738,36 @@ hipError_t fused256s_run(Fused256S<R>* f, hipStream_t s, R* z, R* w, R* x, int B
                          ProxParamsT<R> pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
     const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
-    // chunk: all iterations on `chunk` slices before the next chunk (one queue).  Default for the double engine: 96 slices
-    // (2.5 MiB each: z, w, T, Yh) = a working set inside the 256 MiB Infinity Cache for the whole run.  Measured at 512
-    // slices, 50 CNC iterations: 2419 / 2418 it/s against 2186 / 2400 for two queues over the whole batch, which falls into
-    // a slow mode on some boxes and runs (64: 2325, 128: 2390).  sch.chunk < 0 (PNP_FUSED_CHUNK=-1): off.
-    const int chunk_req = sch.chunk != 0 ? sch.chunk : (sizeof(R) == 8 ? 96 : 0);
-    if (sch.queues < 2 || B < 64 || chunk_req > 0) {
-        int chunk = chunk_req > 0 ? (chunk_req & ~1) : B;
-        if (chunk < 2) chunk = 2;
-        hipError_t e = hipSuccess;
+    // chunked round-robin schedule: internal.h, chunk_plan.  sch.chunk < 0 (PNP_FUSED_CHUNK=-1): two halves of the batch on
+    // two queues (the round-1 schedule); PNP_F256S_QUEUES overrides the number of queues (experiments).
+    const char* ev = getenv("PNP_F256S_QUEUES");
+    const ChunkPlan plan = chunk_plan(B, sch, false, sizeof(R) == 8, ev ? atoi(ev) : 0);
+    const int Q = plan.queues, chunk = plan.chunk;
+    hipError_t e = hipSuccess;
+    if (Q < 2 || B <= chunk) {
         for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
             e = run_chunk2<R>(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
         return e;
     }
-    // two halves of the batch on two HIP queues: the heads and tails of one half's launches overlap the other's
-    hipError_t e = hipSuccess;
-    if (!f->side) {
-        e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming);
-        if (e != hipSuccess) return e;
+    if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
+    for (int q = 1; q < Q && e == hipSuccess; ++q) {
+        if (!f->side[q]) {
+            e = hipStreamCreateWithFlags(&f->side[q], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join[q], hipEventDisableTiming);
+        }
     }
-    const int BA = ((B / 2) + 1) & ~1;
+    if (e != hipSuccess) return e;
     e = hipEventRecord(f->ev_fork, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(f->side, f->ev_fork, 0);
-    if (e == hipSuccess) e = run_chunk2<R>(f, s, z, w, x, 0, BA, iters, prox, dc_c, pp);
-    if (e == hipSuccess) e = run_chunk2<R>(f, f->side, z, w, x, BA, B - BA, iters, prox, dc_c, pp);
-    if (e == hipSuccess) e = hipEventRecord(f->ev_join, f->side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join, 0);
+    for (int q = 1; q < Q && e == hipSuccess; ++q) e = hipStreamWaitEvent(f->side[q], f->ev_fork, 0);
+    int k = 0;
+    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk, ++k) {
+        const int q = k % Q;
+        e = run_chunk2<R>(f, q ? f->side[q] : s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
+    }
+    for (int q = 1; q < Q && e == hipSuccess; ++q) {
+        e = hipEventRecord(f->ev_join[q], f->side[q]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join[q], 0);
+    }
     return e;
 }
 

@@ -32,6 +32,9 @@ struct Fused512 {
     c32* T = nullptr;
     float4* Yh = nullptr;
     unsigned long long* Mh = nullptr;
+    static constexpr int MAXQ = 4;
+    hipStream_t side[MAXQ] = {};              // further queues of the chunked schedule (fused512_run); [0] unused
+    hipEvent_t ev_fork = nullptr, ev_join[MAXQ] = {};
 };
 
 constexpr int NN5 = 512 * 512;
@@ -309,6 +312,11 @@ void fused512_destroy(Fused512* f) {
     if (f->T) (void)hipFree(f->T);
     if (f->Yh) (void)hipFree(f->Yh);
     if (f->Mh) (void)hipFree(f->Mh);
+    for (int q = 1; q < Fused512::MAXQ; ++q) {
+        if (f->side[q]) (void)hipStreamDestroy(f->side[q]);
+        if (f->ev_join[q]) (void)hipEventDestroy(f->ev_join[q]);
+    }
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     delete f;
 }
 
@@ -358,6 +366,11 @@ static hipError_t run5_chunk(Fused512* f, hipStream_t s, float* z, float* w, flo
     return e;
 }
 
+static int env_queues() {
+    const char* v = getenv("PNP_F512_QUEUES");
+    return v ? atoi(v) : 0;
+}
+
 hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
                         float dc_c, ProxParams pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
@@ -366,17 +379,36 @@ hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x
     // 0.49 ms against 0.451 ms per iteration at 256 slices -- the 240-VGPR column body would drag
     // the row body down to 2 waves/SIMD in a mixed launch), so the queue / mixed knobs of
     // FusedSchedule apply to the 256x256 path only.
-    // All iterations on `chunk` slices before the next chunk: 4 MiB per slice (z, w, T, Yh), so 48 slices keep a chunk's
-    // whole working set inside the 256 MiB Infinity Cache for the run.  Measured at 256 slices, 100 CNC iterations, one box,
-    // 4 alternating repetitions: 48 -> 1161-1162 it/s, 128 -> 1155-1159, whole batch -> 1057-1060 on that box (the whole
-    // batch runs 1165 on other boxes and runs: a slow mode the chunks avoid); 32 -> 1008.  sch.chunk (PNP_FUSED_CHUNK)
-    // overrides; < 0 = whole batch.
-    const int chunk_req = sch.chunk != 0 ? sch.chunk : 48;
-    int chunk = chunk_req > 0 ? (chunk_req & ~1) : B;
-    if (chunk < 2) chunk = 2;
+    // chunked round-robin schedule: internal.h, chunk_plan (4 MiB per slice: z, w, T, Yh).  sch.chunk (PNP_FUSED_CHUNK) overrides
+    // the chunk size, < 0 = whole batch; PNP_F512_QUEUES overrides the number of queues (experiments).
+    const ChunkPlan plan = chunk_plan(B, sch, true, false, env_queues());
+    const int Q = plan.queues, chunk = plan.chunk;
     hipError_t e = hipSuccess;
-    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
-        e = run5_chunk(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
+    if (Q < 2 || B <= chunk) {
+        for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk)
+            e = run5_chunk(f, s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
+        return e;
+    }
+    // chunks go round-robin to Q queues: Q chunks in flight, each queue runs all iterations of its chunk before its next one
+    if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
+    for (int q = 1; q < Q && e == hipSuccess; ++q) {
+        if (!f->side[q]) {
+            e = hipStreamCreateWithFlags(&f->side[q], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_join[q], hipEventDisableTiming);
+        }
+    }
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(f->ev_fork, s);
+    for (int q = 1; q < Q && e == hipSuccess; ++q) e = hipStreamWaitEvent(f->side[q], f->ev_fork, 0);
+    int k = 0;
+    for (int c0 = 0; c0 < B && e == hipSuccess; c0 += chunk, ++k) {
+        const int q = k % Q;
+        e = run5_chunk(f, q ? f->side[q] : s, z, w, x, c0, (B - c0 < chunk) ? (B - c0) : chunk, iters, prox, dc_c, pp);
+    }
+    for (int q = 1; q < Q && e == hipSuccess; ++q) {
+        e = hipEventRecord(f->ev_join[q], f->side[q]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, f->ev_join[q], 0);
+    }
     return e;
 }
 
