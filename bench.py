@@ -290,7 +290,8 @@ def main():
                        'slices_per_gpu': B, 'path': eng.path_name, 'precision': args.precision,
                        # 0 = the iterations of a call are a loop inside ONE launch (slice-resident kernel)
                        'launches_per_iteration': eng.kernels_per_iteration,
-                       'queues': sched['queues'], 'mixed_row_col_launches': bool(sched['mixed'])},
+                       'queues': eng.plan['queues'], 'slices_per_chunk': eng.plan['chunk'],
+                       'mixed_row_col_launches': bool(sched['mixed'])},
             'slice_iterations_per_s': value * B_PER_GPU,
             'hip_event_ms_per_step': ev_ms / K,
             'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,

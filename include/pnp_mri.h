@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   6
+#define PNP_ABI_VERSION   7
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -68,6 +68,10 @@ int pnp_set_fast_path(pnp_ctx* ctx, int enable);
 int pnp_set_schedule(pnp_ctx* ctx, int queues, int mixed_launches, int chunk);
 /* the schedule in force (any pointer may be NULL) */
 int pnp_get_schedule(pnp_ctx* ctx, int* queues, int* mixed_launches, int* chunk);
+/* what the next pnp_admm_*_run will do for the uploaded batch on the path in use: HIP queues, slices per chunk (the batch
+ * size when it is not chunked), kernel launches per batched iteration (0: slice-resident, the iterations are a loop inside one
+ * launch).  Any pointer may be NULL.  New in ABI 7; no counterpart in the reference. */
+int pnp_get_plan(pnp_ctx* ctx, int* queues, int* chunk, int* launches_per_iteration);
 
 /* ---- problem upload ---------------------------------------------------------------------- */
 /* y: [B][H][W] complex64, the measurements  y = fft2(img)*mask + noises  (S4:102).

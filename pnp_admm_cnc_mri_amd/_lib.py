@@ -30,6 +30,7 @@ SIGNATURES = {
     'pnp_set_fast_path': (C.c_int, [ctx_p, C.c_int]),
     'pnp_set_schedule': (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int]),
     'pnp_get_schedule': (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'pnp_get_plan': (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'pnp_upload_problem': (C.c_int, [ctx_p, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     'pnp_synthesize_problem': (C.c_int, [ctx_p, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     'pnp_download_y': (C.c_int, [ctx_p, _vp, C.c_int]),
@@ -64,7 +65,7 @@ SIGNATURES = {
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -713,6 +713,26 @@ int pnp_timer_stop(pnp_ctx* c, float* ms) {
     return PNP_OK;
 }
 
+int pnp_get_plan(pnp_ctx* c, int* queues, int* chunk, int* launches_per_iteration) {
+    CTX(c);
+    int q = 1, ch = c->B;
+    if (use_fused(c) && !(c->slice && c->slice_ready)) {
+        if (c->fs32 || c->fs64 || c->fused5) {
+            const char* ev = getenv(c->fused5 ? "PNP_F512_QUEUES" : "PNP_F256S_QUEUES");
+            const ChunkPlan p = chunk_plan(c->B, c->sched, c->fused5 != nullptr, c->fs64 != nullptr, ev ? atoi(ev) : 0);
+            q = p.queues; ch = p.chunk < c->B ? p.chunk : c->B;
+        } else if (c->sched.chunk > 0) {
+            ch = c->sched.chunk < c->B ? c->sched.chunk : c->B;
+        } else if (c->sched.queues >= 2 && c->B >= 32 * c->sched.queues) {
+            q = c->sched.queues;
+        }
+    }
+    if (queues) *queues = q;
+    if (chunk) *chunk = ch;
+    if (launches_per_iteration) *launches_per_iteration = pnp_kernels_per_iteration(c);
+    return PNP_OK;
+}
+
 int pnp_kernels_per_iteration(pnp_ctx* c) {
     if (!c) return 0;
     if (!use_fused(c)) return 3;                      // generic: rows, columns, rows

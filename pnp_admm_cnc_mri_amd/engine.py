@@ -84,6 +84,13 @@ class Engine:
         return {'queues': q.value, 'mixed': m.value, 'chunk': ch.value}
 
     @property
+    def plan(self):
+        """What the next loop call does for the uploaded batch: {'queues', 'chunk', 'launches_per_iteration'} (pnp_get_plan)."""
+        q, ch, n = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._L.pnp_get_plan(self._ctx, C.byref(q), C.byref(ch), C.byref(n)))
+        return {'queues': q.value, 'chunk': ch.value, 'launches_per_iteration': n.value}
+
+    @property
     def path_name(self):
         return self._L.pnp_path_name(self._ctx).decode()
 

@@ -419,3 +419,24 @@ def test_chunked_default_schedules_are_bit_identical(env, H, precision, B, iters
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert np.array_equal(a, b)
+
+
+def test_plan_reports_what_the_loops_will_do(env):
+    """pnp_get_plan: queues / slices per chunk / launches per iteration of the next run, per path."""
+    P = env['P']
+    mask = np.ones((256, 256), np.uint8)
+    with P.Engine(256, 256, Bmax=512) as eng:
+        eng.upload(np.zeros((512, 256, 256), np.complex64), mask)
+        assert eng.path_name == 'slice' and eng.plan == {'queues': 1, 'chunk': 512, 'launches_per_iteration': 0}
+        eng.upload(np.zeros((40, 256, 256), np.complex64), mask)
+        assert eng.path_name == 'fused' and eng.plan['launches_per_iteration'] == 2 * eng.plan['queues']
+    with P.Engine(512, 512, Bmax=64) as eng:
+        eng.upload(np.zeros((52, 512, 512), np.complex64), np.ones((512, 512), np.uint8))
+        assert eng.plan == {'queues': 4, 'chunk': 16, 'launches_per_iteration': 8}
+        eng.set_schedule(queues=1, mixed_launches=False, chunk=0)
+        assert eng.plan == {'queues': 1, 'chunk': 48, 'launches_per_iteration': 4}
+        eng.set_schedule(queues=2, mixed_launches=False, chunk=-1)
+        assert eng.plan == {'queues': 1, 'chunk': 52, 'launches_per_iteration': 2}
+    with P.Engine(256, 256, Bmax=100, precision='f64') as eng:
+        eng.upload(np.zeros((100, 256, 256), np.complex64), mask)
+        assert eng.plan == {'queues': 4, 'chunk': 24, 'launches_per_iteration': 10}
