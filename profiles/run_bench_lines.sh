@@ -11,6 +11,7 @@ python3 bench.py --solver l1 --no-cpu-baseline > $O/l1_100.json 2>/dev/null
 python3 bench.py --precision f64 --steps 50 --warmup 5 --no-cpu-baseline > $O/f64_50.json 2>/dev/null
 python3 bench.py --precision f64 --generic --steps 20 --warmup 2 --no-cpu-baseline > $O/f64_generic_20.json 2>/dev/null
 python3 bench.py --size 512 --batch 256 --no-cpu-baseline > $O/size512_100.json 2>/dev/null
+python3 bench.py --size 512 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/size512_driver_shape.json 2>/dev/null
 python3 bench.py --generic --no-cpu-baseline > $O/generic_100.json 2>/dev/null
 python3 bench.py --gpus 2 --rehearse-gloo --steps 20 --warmup 5 > $O/gpus2_rehearsal.json 2>/dev/null
 python3 bench.py --batch 1024 --no-cpu-baseline > $O/batch1024_100.json 2>/dev/null
