@@ -91,3 +91,33 @@ def test_path_selection_by_batch_size(P, monkeypatch):
     with P.Engine(256, 256, Bmax=512) as eng:
         eng.upload(np.zeros((512, 256, 256), np.complex64), mask)
         assert eng.path_name == 'fused'
+
+
+def test_slice_resident_runs_are_bitwise_repeatable(P, monkeypatch):
+    """The kernel hands data between lanes and waves through LDS (exchanges, transpositions, one LDS-DMA prefetch for the
+    packed column) under barriers and wait counts placed by hand or by the compiler: a missing wait shows as results
+    that change from run to run.  40 identical runs of a two-round batch (300 slices > 256 compute units) with different
+    masks per slice must agree to the bit, for x and for the state."""
+    monkeypatch.setenv('PNP_SLICE', '1')
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    m = S.reference_masks()
+    masks = np.stack([m['Q_Random30'], m['Q_Cartesian30'], m['Q_Radial30']]).astype(np.uint8)
+    B = 300
+    img, noise = S.batch(7, B)
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.synthesize(img, noise, masks, np.arange(B) % 3)
+        assert eng.path_name == 'slice'
+        ref = None
+        for rep in range(40):
+            eng.init_state()
+            if rep % 2:
+                eng.admm_cnc(5, 0.45, 0.5, 0.05, 64)
+            else:                                   # the same 5 iterations as two launches
+                eng.admm_cnc(2, 0.45, 0.5, 0.05, 64)
+                eng.admm_cnc(3, 0.45, 0.5, 0.05, 64)
+            got = (eng.x(), *eng.get_state())
+            if ref is None:
+                ref = got
+            else:
+                for a, b in zip(ref, got):
+                    assert np.array_equal(a, b), rep
