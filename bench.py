@@ -98,40 +98,70 @@ def cpu_baseline_all_cores(budget_s=8.0, iters=100):
                       % (cores, budget_s, iters, sum(n for n, _ in res), wall)}
 
 
-def launch_ranks(n):
+def launch_ranks(n, timeout_s):
     """`python bench.py --gpus N` outside torchrun: start the N rank processes as CHILDREN of this
     process (which has not imported torch and never initialises HIP), one per GPU, with the
     torch.distributed env of a one-node job on 127.0.0.1; relay rank 0's JSON line and return the
-    worst exit code.  No exec of an initialised process, no hop under a profiler."""
+    worst exit code.  No exec of an initialised process, no hop under a profiler.
+    A rank that dies takes the job down; a rank that hangs (rendezvous, collective) does so until
+    `timeout_s`, then every child is terminated, killed if need be, and the exit code is 124."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(('127.0.0.1', 0))
         port = so.getsockname()[1]
-    import tempfile
-    procs = []
-    with tempfile.TemporaryFile() as out0:
-        for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
-        rc = 0
-        live = list(procs)
-        while live:                                      # a rank that dies takes the job down, not into a hang
-            time.sleep(0.05)
-            for p in list(live):
-                code = p.poll()
-                if code is None:
-                    continue
-                live.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in live:
-                        q.terminate()
-        out0.seek(0)
-        sys.stdout.write(out0.read().decode())
-        sys.stdout.flush()
+    procs, outs = [], []
+    deadline = time.monotonic() + timeout_s
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        # RCCL shares device buffers between the rank processes of a node through HIP IPC handles.  The host
+        # driver of this pool supports only the dmabuf form (hipIpcGetMemHandle fails with "invalid argument"
+        # in legacy mode), which HSA_ENABLE_IPC_MODE_LEGACY=0 selects; the image exports it, a caller's own
+        # value wins (DESIGN.md section 6).
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        outs.append(tempfile.TemporaryFile())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=outs[r]))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        if time.monotonic() > deadline:
+            sys.stderr.write('bench.py: ranks still running after %.0f s: terminating them\n' % timeout_s)
+            for q in live:
+                q.terminate()
+            t_kill = time.monotonic() + 10
+            while any(q.poll() is None for q in live) and time.monotonic() < t_kill:
+                time.sleep(0.1)
+            for q in live:
+                if q.poll() is None:
+                    q.kill()
+            rc = 124
+            break
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in live:
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except Exception:
+            p.kill()
+    for r, fo in enumerate(outs):
+        fo.seek(0)
+        text = fo.read().decode(errors='replace')
+        fo.close()
+        if r == 0:
+            sys.stdout.write(text)
+            sys.stdout.flush()
+        elif rc != 0 and text:                          # what a failed job's other ranks printed
+            sys.stderr.write('--- stdout of rank %d ---\n%s\n' % (r, text))
     return rc
 
 
@@ -150,12 +180,16 @@ def main():
                          "iterations, DESIGN.md section 2); the headline stays f32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)),
+                    help='--gpus N without torchrun: seconds after which hanging rank processes are killed (exit 124)')
+    ap.add_argument('--no-f64-record', action='store_true',
+                    help="skip the double-precision engine's sub-record (N = 1, headline configuration only)")
     ap.add_argument('--rehearse-gloo', action='store_true',
                     help='rehearsal of the N>1 launch path on a box with ONE GPU: gloo backend, all ranks on cuda:0')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(launch_ranks(args.gpus))               # parent: never touches the GPU
+        sys.exit(launch_ranks(args.gpus, args.launch_timeout))        # parent: never touches the GPU
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -213,27 +247,36 @@ def main():
         del y32
     eng.init_state()
 
-    def run(n):
+    def run(e, n):
         if args.solver == 'cnc':
-            eng.admm_cnc(n, PRESET['alpha'], PRESET['lambda1'], PRESET['reo'], PRESET['b'])
+            e.admm_cnc(n, PRESET['alpha'], PRESET['lambda1'], PRESET['reo'], PRESET['b'])
         else:
-            eng.admm_l1(n, 0.1, 0.015)
+            e.admm_l1(n, 0.1, 0.015)
 
-    def fence():
-        eng.sync()
+    def timed(e):
+        """W untimed steps, then K timed ones.  Both ends of the timed region are a device sync on every rank with
+        a job-wide barrier around them; a rank's clock stops at ITS OWN sync, before the closing barrier, so the
+        collective's latency (tens to hundreds of microseconds, against a 2 ms region at the driver's 20 steps) is
+        not booked as step time.  The job's time is the MAX over ranks (all_reduce further down)."""
+        if args.warmup > 0:
+            run(e, args.warmup)
+        e.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.timer_start()
+        run(e, args.steps)
+        ev = e.timer_stop()                                           # HIP events on the kernels' stream; waits for them
+        e.sync()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+        if dist is not None:
+            dist.barrier()
+        return wall, ev
 
-    if args.warmup > 0:
-        run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    run(args.steps)
-    ev_ms = eng.timer_stop()                                          # HIP events on the kernels' stream
-    fence()
-    wall_ms = (time.perf_counter() - t0) * 1e3
+    wall_ms, ev_ms = timed(eng)
 
     # the one collective of the job: gather x on rank 0 over RCCL (timed apart from the steps)
     gather_ms = None
@@ -244,9 +287,13 @@ def main():
         from pnp_admm_cnc_mri_amd import sharding
         torch.cuda.synchronize()
         dist.barrier()
+        xg = x_dev.cpu() if args.rehearse_gloo else x_dev
+        sharding.gather_slices(xg, world * B, dst=0)                   # untimed: the first collective sets up the peer connections
+        torch.cuda.synchronize()
+        dist.barrier()
         tg = time.perf_counter()
-        x_all = sharding.gather_slices(x_dev.cpu() if args.rehearse_gloo else x_dev, world * B, dst=0)
-        torch.cuda.synchronize()                                      # ^ one direct RCCL gather over xGMI
+        x_all = sharding.gather_slices(xg, world * B, dst=0)          # one direct RCCL gather over xGMI
+        torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         assert (x_all is not None) == (rank == 0)
         if rank == 0:
@@ -256,6 +303,57 @@ def main():
         wall_ms, ev_ms, gather_ms = (float(v) for v in t.cpu())
     checksum = float(x_dev.double().sum())
     finite = bool(torch.isfinite(x_dev).all())
+
+    # Checker legs (rank 0 of an N = 1 job, with the CPU baseline): the NumPy oracle runs the same W + K iterations on
+    # three of the slices from the same measurements, so every line re-proves parity of what was timed; and the
+    # double-precision engine -- the configuration that holds 1e-5 against the float64 reference at config 2's own
+    # 100 CNC iterations -- is timed in the same process on the same batch.
+    parity, f64_record = None, None
+    checker = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if checker:
+        from oracle import admm_oracle as O
+        n_it = args.warmup + args.steps
+        picks = sorted({0, B // 2 - 1 if B > 1 else 0, B - 1})
+        y_all = eng.download_y() if args.precision == 'f32' else None
+        if args.precision == 'f64':                                    # the f64 engine holds y in double: rebuild the float32 measurements
+            e32 = P.Engine(H, W, Bmax=B, device=local_rank)
+            e32.synthesize(img, noise, masks, mask_id)
+            y_all = e32.download_y()
+            e32.close()
+        ref = {}
+        for b in picks:
+            y64 = y_all[b].astype(np.complex128)
+            ref[b] = (O.admm_cnc(y64, masks[mask_id[b]], n_it, **PRESET) if args.solver == 'cnc'
+                      else O.admm_l1(y64, masks[mask_id[b]], n_it, lambda1=0.1, reo=0.015))
+
+        def rel(xd):
+            return [float(np.linalg.norm(xd[b].double().cpu().numpy() - ref[b]) / np.linalg.norm(ref[b])) for b in picks]
+        parity = {'rel_l2_vs_oracle': rel(x_dev), 'slices': picks, 'iterations': n_it, 'oracle': 'oracle/admm_oracle.py (NumPy float64)'}
+        if (args.precision == 'f32' and args.size == 256 and args.solver == 'cnc' and not args.generic
+                and not args.no_f64_record):
+            e64 = P.Engine(H, W, Bmax=B, device=local_rank, precision='f64')
+            e64.upload(y_all, masks, mask_id)
+            e64.init_state()
+            w64, ev64 = timed(e64)
+            x64 = torch.empty((B, H, W), dtype=torch.float64, device='cuda')
+            e64.x(out=x64)
+            e64.sync()
+            t64 = None
+            try:
+                t64 = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(
+                    '%s:cnc:256:f64:b%d' % (e64.path_name, B), {}).get('hbm_bytes_per_iteration')
+            except Exception:
+                pass
+            f64_record = {'value': args.steps / (w64 * 1e-3) * (B / B_PER_GPU), 'unit': 'it/s (512-slice batches)',
+                          'ms_per_step': w64 / args.steps, 'hip_event_ms_per_step': ev64 / args.steps,
+                          'dtype': 'f64', 'path': e64.path_name, 'rel_l2_vs_oracle': rel(x64), 'slices': picks,
+                          'iterations': n_it,
+                          'frac': ALG_BYTES_PER_PIXEL * H * W * B / (ev64 / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'traffic': t64,
+                          'frac_measured': None if t64 is None else t64 / (ev64 / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del x64
+            e64.close()
+        del y_all
 
     if rank == 0:
         K = args.steps
@@ -279,7 +377,7 @@ def main():
             sched = {'queues': 1, 'mixed': 0, 'chunk': 0}
         ev_s_per_it = ev_ms * 1e-3 / K
         line = {
-            'metric': 'ADMM iterations/sec on 256x256 complex64 slices (batch=512)',
+            'metric': 'ADMM iterations/sec on %dx%d complex64 slices (batch=512)' % (H, W),
             'value': value, 'unit': 'it/s (512-slice batches)',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -295,6 +393,7 @@ def main():
             'slice_iterations_per_s': value * B_PER_GPU,
             'hip_event_ms_per_step': ev_ms / K,
             'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,
+            'parity': parity, 'f64': f64_record,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          # the physically meaningful pair: bytes the kernels really move (PMC) over the same time
@@ -302,6 +401,7 @@ def main():
                          'frac_measured': None if traffic is None else traffic / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
                          'traffic_over_algorithmic': None if traffic is None else traffic / (alg_bytes / K),
                          'traffic_from': traffic_src,
+                         'traffic_measured_in_this_run': False,       # PMC passes on the builder's box, committed under profiles/
                          'note': 'achieved = 57*H*W*B algorithmic bytes per iteration (SURVEY.md 8d: plain c2c float32 '
                                  'formulation) / HIP-event time per iteration on the kernels\' stream; it exceeds the peak '
                                  'because the kernels move fewer bytes than that formulation (slice-resident path: z, w and the '

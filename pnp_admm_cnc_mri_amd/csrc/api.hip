@@ -85,6 +85,7 @@ struct pnp_ctx {
     Fused256S<double>* fs64 = nullptr;  // ... and in double: the fast path of an fp64 context
     FusedSchedule sched;              // defaults overridable by PNP_FUSED_* (read at creation) / pnp_set_schedule
     bool fused_ready = false;         // tables prepared for the current problem
+    bool fused_tabs = false;          // 256x256 float: the two-launch tables themselves (built on first use when the slice-resident tables serve the loops)
     // fp64 validation context (pnp_ctx_create_f64): same loop, generic kernels, double buffers
     bool f64 = false;
     double2* yd = nullptr;
@@ -179,8 +180,14 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
             c->slice_min_b = mode == 1 ? 1 : env_int("PNP_SLICE_MIN_B", 64);
             c->slice_force = (mode == 1);
             if (c->fused && mode != 0 && Bmax >= c->slice_min_b) {
-                c->slice = slice256_create(Bmax, &fe);
-                if (!c->slice) { fused256_destroy(c->fused); c->fused = nullptr; }
+                hipError_t se = hipSuccess;
+                c->slice = slice256_create(Bmax, &se);
+                // no room for the slice-resident tables (256 KiB per slice on top of the two-launch tables): the context
+                // degrades to the two-launch path (pnp_path_name says "fused") -- unless the caller forced PNP_SLICE=1
+                if (!c->slice) {
+                    (void)hipGetLastError();
+                    if (mode == 1) { fe = se; fused256_destroy(c->fused); c->fused = nullptr; }
+                }
             }
         }
         else                                             c->fused5 = fused512_create(Bmax, &fe);
@@ -288,15 +295,34 @@ static bool slice_pays(pnp_ctx* c) {
     return c->slice_force || c->B >= c->slice_min_b;
 }
 
+static int prepare_fused_tables(pnp_ctx* c);
+// A failed prepare leaves no valid problem behind: B = 0, no table marked ready.
 static int prepare_fused(pnp_ctx* c) {
     c->slice_ready = false;
-    if (c->fused) {
+    c->fused_ready = false;
+    const int rc = prepare_fused_tables(c);
+    if (rc) { c->B = 0; c->slice_ready = false; c->fused_ready = false; }
+    return rc;
+}
+// the two-launch tables of a 256x256 float context: needed by pnp_dc_step and by loops that do not take the slice-resident path
+static int ensure_fused_tabs(pnp_ctx* c) {
+    if (c->fused && !c->fused_tabs) {
         HIPCHK(fused256_prepare(c->fused, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
-        c->fused_ready = true;
+        c->fused_tabs = true;
+    }
+    return PNP_OK;
+}
+static int prepare_fused_tables(pnp_ctx* c) {
+    if (c->fused) {
+        c->fused_tabs = false;
         if (c->slice && slice_pays(c)) {
             HIPCHK(slice256_prepare(c->slice, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
             c->slice_ready = true;
+        } else {
+            const int rc = ensure_fused_tabs(c);
+            if (rc) return rc;
         }
+        c->fused_ready = true;
     } else if (c->fused5) {
         HIPCHK(fused512_prepare(c->fused5, c->stream, c->y, c->mask_bank, c->mask_id, c->B));
         c->fused_ready = true;
@@ -457,7 +483,7 @@ static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, doubl
     const float cdc = dc_coeff(reo);
     if (use_fused(c)) {
         if (c->slice && c->slice_ready) HIPCHK(slice256_run(c->slice, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
-        else if (c->fused)  HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
+        else if (c->fused)  { const int rt = ensure_fused_tabs(c); if (rt) return rt; HIPCHK(fused256_run(c->fused, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched)); }
         else if (c->fs32)   HIPCHK(fused256s_run<float>(c->fs32, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
         else                HIPCHK(fused512_run(c->fused5, c->stream, c->z, c->w, c->x, c->B, iters, cnc, cdc, pp, c->sched));
     } else {
@@ -508,7 +534,7 @@ int pnp_dc_step(pnp_ctx* c, const float* z, const float* w, float* x, double reo
     if (!z || !w || !x) return fail(PNP_E_ARG, "pnp_dc_step: null pointer");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "pnp_dc_step: reo must be > 0");
     if (use_fused(c)) {
-        if (c->fused)     HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo)));
+        if (c->fused)     { const int rt = ensure_fused_tabs(c); if (rt) return rt; HIPCHK(fused256_dc(c->fused, c->stream, z, w, x, c->B, dc_coeff(reo))); }
         else if (c->fs32) HIPCHK(fused256s_dc<float>(c->fs32, c->stream, z, w, x, c->B, dc_coeff(reo)));
         else              HIPCHK(fused512_dc(c->fused5, c->stream, z, w, x, c->B, dc_coeff(reo)));
         return PNP_OK;

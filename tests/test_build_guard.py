@@ -1,0 +1,162 @@
+"""Build-time guards for the hand-tuned gfx950 kernels (CPU only: hipcc cross-compiles without a GPU).
+
+The slice-resident kernel sits on a resource cliff: 256 VGPRs x 512 threads is the whole
+register file of a compute unit, a spill or a second code instance halves the headline, and a
+`buffer_store_dwordx4` with an SGPR soffset directly followed by a VALU write to its data registers stores the
+NEW value on gfx950 (hipcc only protects the form with a constant soffset).  A compiler bump or an innocent
+edit can bring any of these back silently, so this file compiles the kernels to gfx950 assembly
+(`hipcc --cuda-device-only -S`, the Makefile's flags) and asserts what the measurements depend on:
+
+  * k_slice<1|2|3>: 0 bytes of scratch, <= 256 VGPRs, 2 waves per SIMD, LDS <= 160 KiB, code size bounded;
+  * k5_cols (512x512 column kernel): <= 168 VGPRs (3 waves per SIMD stay possible), 0 scratch;
+  * every kernel of the library: no >= 96-bit buffer store with an SGPR soffset whose data registers are
+    written by a VALU instruction inside the hazard window.
+"""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, 'pnp_admm_cnc_mri_amd', 'csrc')
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'api.hip']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off']     # = csrc/Makefile CXXFLAGS
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+
+
+def _compile(args):
+    src, out = args
+    r = subprocess.run([HIPCC] + FLAGS + ['--cuda-device-only', '-S', os.path.join(CSRC, src), '-o', out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=CSRC)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return out
+
+
+@pytest.fixture(scope='module')
+def asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp('gfx950_asm')
+    jobs = [(s, str(d / (s[:-4] + '.s'))) for s in SOURCES]
+    with ThreadPoolExecutor(3) as ex:
+        outs = list(ex.map(_compile, jobs))
+    return {s: open(o).read() for s, o in zip(SOURCES, outs)}
+
+
+def kernels_of(text):
+    """{mangled kernel name: {'body': [instruction lines], 'info': {key: int}}} of one assembly file."""
+    res = {}
+    lines = text.splitlines()
+    i = 0
+    while i < len(lines):
+        m = re.match(r'^(_Z\w+):\s*(;.*)?$', lines[i])
+        if not m:
+            i += 1
+            continue
+        name, body = m.group(1), []
+        i += 1
+        while i < len(lines) and not lines[i].startswith('.Lfunc_end'):
+            ln = lines[i].strip()
+            if ln and not ln.startswith((';', '.')) and not ln.endswith(':'):
+                body.append(ln.split(';')[0].strip())
+            i += 1
+        info = {}
+        while i < len(lines) and not re.match(r'^_Z\w+:', lines[i]):
+            mm = re.match(r'^; (codeLenInByte|NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|TotalNumSgprs)\s*[:=]\s*(\d+)', lines[i])
+            if mm:
+                info[mm.group(1)] = int(mm.group(2))
+            if lines[i].startswith('; COMPUTE_PGM_RSRC2:TGID_Z_EN'):
+                break
+            i += 1
+        if 'codeLenInByte' in info:
+            res[name] = {'body': body, 'info': info}
+    return res
+
+
+def test_slice_resident_kernel_stays_off_the_cliff(asm):
+    ks = {n: k for n, k in kernels_of(asm['kernels_slice256.hip']).items() if 'k_slice' in n}
+    assert len(ks) == 3, sorted(ks)                                  # PROX = 1, 2, 3
+    for name, k in ks.items():
+        i = k['info']
+        assert i['ScratchSize'] == 0, (name, i)                      # a spill costs 10-30 % ("how it got there")
+        assert i['NumVgprs'] + i['NumAgprs'] <= 256, (name, i)
+        assert i['Occupancy'] == 2, (name, i)                        # 8 waves x 256 VGPRs = one workgroup per compute unit
+        assert i['LDSByteSize'] <= 160 * 1024, (name, i)
+        # the loop body does not fit the 64 KiB instruction cache either way (measured with 84-92 KB); what must not
+        # come back is the 116 KB of two row-phase instances
+        assert i['codeLenInByte'] <= 96 * 1024, (name, i)
+
+
+def test_512_column_kernel_register_budget(asm):
+    ks = {n: k for n, k in kernels_of(asm['kernels_fused512.hip']).items() if 'k5_cols' in n}
+    assert ks
+    for name, k in ks.items():
+        assert k['info']['ScratchSize'] == 0 and k['info']['NumVgprs'] <= 168, (name, k['info'])
+
+
+def _regs(tok):
+    """VGPR numbers named by an operand token: 'v12' -> {12}, 'v[4:7]' -> {4,5,6,7}, anything else -> {}"""
+    m = re.fullmatch(r'v(\d+)', tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def _valu_dest(ins):
+    """VGPRs written by a VALU instruction (first operand of v_* except compares / readlanes, which write SGPRs)."""
+    op, _, rest = ins.partition(' ')
+    if not op.startswith('v_') or op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane', 'v_nop')):
+        return set()
+    return _regs(rest.split(',')[0].strip())
+
+
+def store_hazards(body, window=2):
+    """buffer_store_dwordx3/x4 with an SGPR soffset followed, within `window` wait states, by a VALU write to the
+    store's data registers.  Every instruction counts as one wait state, s_nop N as N + 1."""
+    bad = []
+    for i, ins in enumerate(body):
+        m = re.match(r'buffer_store_dwordx[34]\s+(v\[\d+:\d+\]),\s*([^,]+),\s*(s\[\d+:\d+\]),\s*(\S+)', ins)
+        if not m:
+            continue
+        soffset = m.group(4).rstrip(',')
+        if not re.fullmatch(r's\d+|m0|ttmp\d+', soffset):           # constant soffset: hipcc inserts the wait states itself
+            continue
+        data, ws, j = _regs(m.group(1)), 0, i + 1
+        while j < len(body) and ws < window:
+            nxt = body[j]
+            if _valu_dest(nxt) & data:
+                bad.append((ins, nxt))
+                break
+            mm = re.match(r's_nop\s+(\d+)', nxt)
+            ws += int(mm.group(1)) + 1 if mm else 1
+            j += 1
+    return bad
+
+
+def test_hazard_scanner_sees_the_pattern_that_bit_us():
+    """the sequence of DESIGN.md section 4.1 ("Buffer-store hazard") and its harmless neighbours"""
+    assert store_hazards(['buffer_store_dwordx4 v[28:31], v224, s[48:51], s83 offen', 'v_mov_b32_e32 v28, v5'])
+    assert store_hazards(['buffer_store_dwordx4 v[28:31], v224, s[48:51], s83 offen', 's_add_u32 s1, s2, s3',
+                          'v_pk_add_f32 v[30:31], v[2:3], v[4:5]'])
+    assert not store_hazards(['buffer_store_dwordx4 v[28:31], v224, s[48:51], 0 offen', 'v_mov_b32_e32 v28, v5'])
+    assert not store_hazards(['buffer_store_dwordx4 v[28:31], v224, s[48:51], s83 offen', 's_nop 1', 'v_mov_b32_e32 v28, v5'])
+    assert not store_hazards(['buffer_store_dwordx4 v[28:31], v224, s[48:51], s83 offen', 'v_mov_b32_e32 v32, v5',
+                              'v_cmp_lt_f32_e32 vcc, v28, v29'])
+    assert not store_hazards(['buffer_store_dwordx2 v[28:29], v224, s[48:51], s83 offen', 'v_mov_b32_e32 v28, v5'])
+
+
+def test_no_wide_buffer_store_is_overwritten_in_its_hazard_window(asm):
+    n_stores = 0
+    for src, text in asm.items():
+        for name, k in kernels_of(text).items():
+            n_stores += sum(1 for ins in k['body'] if ins.startswith('buffer_store_dwordx4'))
+            bad = store_hazards(k['body'])
+            assert not bad, '%s: %s: %s' % (src, name, bad[:3])
+    assert n_stores >= 100                                           # the slice kernel's state stores were really scanned

@@ -40,6 +40,38 @@ def torch():
     return torch
 
 
+PATHS = ('generic', 'fused', 'slice')
+
+
+class _engine_on:
+    """Engine forced onto one of the three kernel families: 'generic' (set_fast_path(0)), 'fused' (two-launch,
+    PNP_SLICE=0) or 'slice' (the slice-resident kernel bench.py times, PNP_SLICE=1 so that it also takes a batch
+    of one slice).  check() asserts pnp_path_name after the problem is uploaded."""
+
+    def __init__(self, P, path, H=256, W=256, Bmax=1):
+        self.P, self.path, self.args = P, path, (H, W, Bmax)
+
+    def __enter__(self):
+        self.saved = os.environ.get('PNP_SLICE')
+        os.environ['PNP_SLICE'] = '1' if self.path == 'slice' else '0'
+        try:
+            self.eng = self.P.Engine(self.args[0], self.args[1], Bmax=self.args[2])
+        finally:
+            if self.saved is None:
+                os.environ.pop('PNP_SLICE', None)
+            else:
+                os.environ['PNP_SLICE'] = self.saved
+        self.eng.set_fast_path(0 if self.path == 'generic' else 1)
+        self.eng.check = lambda: self._check()
+        return self.eng
+
+    def _check(self):
+        assert self.eng.path_name == self.path, (self.eng.path_name, self.path)
+
+    def __exit__(self, *exc):
+        self.eng.close()
+
+
 def _masks(golden_inputs):
     return np.stack([golden_inputs['masks'][MASKS[k]] for k in ('random30', 'radial30', 'cartesian30')]).astype(np.uint8)
 
@@ -174,14 +206,14 @@ def test_prox_kernels(P, torch):
 # ------------------------------------------------------------------------------------------------
 # whole solves against the golden vectors of the unmodified reference (config 1)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('fast', [0, 1])
+@pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('n', [1, 2, 5, 10, 50])
-def test_admm_l1_golden(P, golden_inputs, golden_admm, n, fast):
+def test_admm_l1_golden(P, golden_inputs, golden_admm, n, path):
     img = O.requantise(golden_inputs['gray'])
     mask = golden_inputs['masks']['Q_Random30']
-    with P.Engine(256, 256, Bmax=1) as eng:
-        eng.set_fast_path(fast)
+    with _engine_on(P, path) as eng:
         eng.synthesize(img, golden_inputs['noises'], mask)
+        eng.check()
         eng.init_state()
         eng.admm_l1(n, 0.1, 0.015)                     # S1:171 presets
         x = eng.x()[0]
@@ -191,14 +223,14 @@ def test_admm_l1_golden(P, golden_inputs, golden_admm, n, fast):
     assert abs(O.calculate_psnr(x.astype(np.float64) * 255, gt) - O.calculate_psnr(ref.astype(np.float64) * 255, gt)) <= 0.01
 
 
-@pytest.mark.parametrize('fast', [0, 1])
+@pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('n', [1, 2, 5, 10, 50])
-def test_admm_cnc_golden(P, golden_inputs, golden_admm, n, fast):
+def test_admm_cnc_golden(P, golden_inputs, golden_admm, n, path):
     img = O.requantise(golden_inputs['gray'])
     mask = golden_inputs['masks']['Q_Random30']
-    with P.Engine(256, 256, Bmax=1) as eng:
-        eng.set_fast_path(fast)
+    with _engine_on(P, path) as eng:
         eng.synthesize(img, golden_inputs['noises'], mask)
+        eng.check()
         eng.init_state()
         eng.admm_cnc(n, 0.45, 0.5, 0.05, 64)           # S4:176 presets (expansive: reo*lambda*b = 1.6)
         x = eng.x()[0]
@@ -225,12 +257,14 @@ def test_solver_entry_points_on_reference_inputs(P, golden_inputs, golden_admm, 
     assert abs(info['psnr'][0] - 24.5765) <= 0.01 and abs(info['re'][0] - 0.1870) <= 1e-4
 
 
+@pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('mname', ['radial30', 'cartesian30'])
-def test_other_masks_golden(P, golden_inputs, golden_admm, mname):
+def test_other_masks_golden(P, golden_inputs, golden_admm, mname, path):
     img = O.requantise(golden_inputs['gray'])
     mask = golden_inputs['masks'][MASKS[mname]]
-    with P.Engine(256, 256, Bmax=1) as eng:
+    with _engine_on(P, path) as eng:
         eng.synthesize(img, golden_inputs['noises'], mask)
+        eng.check()
         eng.init_state()
         eng.admm_l1(50, 0.1, 0.015)
         assert rel_l2(eng.x()[0], golden_admm['l1_%s_it50' % mname]) <= 1e-5
@@ -259,8 +293,8 @@ def test_batched_mixed_masks_vs_oracle(P, golden_inputs, B, fast):
         assert rel_l2(xcnc[b], O.admm_cnc(y64, masks[mid[b]], 30, 0.45, 0.5, 0.05, 64)) <= 1e-5, b
 
 
-@pytest.mark.parametrize('fast', [0, 1])
-def test_cnc_100_iterations_config2(P, golden_inputs, fast):
+@pytest.mark.parametrize('path', PATHS)
+def test_cnc_100_iterations_config2(P, golden_inputs, path):
     """Config 2's iteration count (100) with the committed CNC presets.  The map is locally
     expansive, so fp32 round-off grows ~1.08x per iteration in any fp32 arithmetic: NumPy's own
     complex64/float32 run of the same lines ends 4e-4 away from the float64 reference.  Pinned:
@@ -274,9 +308,9 @@ def test_cnc_100_iterations_config2(P, golden_inputs, fast):
     y64 = [ys[b].astype(np.complex64).astype(np.complex128) for b in range(B)]
     marks = (24, 49, 74, 98, 99)
     traces = [O.admm_cnc(y64[b], masks[0], 100, trace=marks + (25, 50, 75, 100))[1] for b in range(B)]
-    with P.Engine(256, 256, Bmax=B) as eng:
-        eng.set_fast_path(fast)
+    with _engine_on(P, path, Bmax=B) as eng:
         eng.upload(ys, masks, mid)
+        eng.check()
         for it in (24, 49, 74, 98):                                        # (a)
             z = np.stack([traces[b][it][1] for b in range(B)]).astype(np.float32)
             w = np.stack([traces[b][it][2] for b in range(B)]).astype(np.float32)

@@ -440,3 +440,39 @@ def test_plan_reports_what_the_loops_will_do(env):
     with P.Engine(256, 256, Bmax=100, precision='f64') as eng:
         eng.upload(np.zeros((100, 256, 256), np.complex64), mask)
         assert eng.plan == {'queues': 4, 'chunk': 24, 'launches_per_iteration': 10}
+
+
+def test_bench_runs_its_collectives_on_rccl_with_one_rank():
+    """The N > 1 code path of bench.py on the real backend: PNP_BENCH_FORCE_DIST=1 makes a one-rank job initialise
+    the 'nccl' (= RCCL) process group and run the barriers, the device-tensor gather and the MAX all-reduce.  Same
+    slices, same iterations as the plain run: the checksum must be equal and the line complete."""
+    env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '64', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    r = subprocess.run(base, env=dict(env_, PNP_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert j['n_gpus'] == 1 and j['gather_ms'] is not None and j['gather_ms'] > 0 and j['x_finite']
+    assert j['config']['path'] == 'slice'
+    r1 = subprocess.run(base, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    j1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert j1['gather_ms'] is None and j1['x_checksum'] == j['x_checksum']
+
+
+def test_bench_line_carries_parity_and_the_f64_record():
+    """With the CPU legs on, rank 0 of an N = 1 job re-proves parity of the timed run against the oracle (three slices,
+    W + K iterations) and times the double-precision engine in the same process."""
+    env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '64', '--steps', '8', '--warmup', '2',
+                        '--cpu-budget', '1'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert j['parity']['iterations'] == 10 and len(j['parity']['rel_l2_vs_oracle']) == 3
+    assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5
+    assert j['f64']['dtype'] == 'f64' and j['f64']['value'] > 0 and max(j['f64']['rel_l2_vs_oracle']) <= 1e-9
+    assert j['cpu_baseline']['cores'] == 1 and j['roofline']['traffic_measured_in_this_run'] is False

@@ -121,3 +121,60 @@ def test_slice_resident_runs_are_bitwise_repeatable(P, monkeypatch):
             else:
                 for a, b in zip(ref, got):
                     assert np.array_equal(a, b), rep
+
+
+@pytest.mark.parametrize('B', [1, 2, 63, 64, 65, 255, 256, 257, 300])
+def test_slice_path_at_every_batch_shape(P, B, monkeypatch):
+    """Batch sizes around the 64-slice selection threshold and around one round of 256 compute units (a second round
+    of one slice, of 44): the slice-resident loops against the two-launch path for x, z, w (values in [0, 1]:
+    max-abs <= 2e-5; measured 6.2e-6) and against the oracle on the first, middle and last slice."""
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    m = S.reference_masks()
+    masks = np.stack([m['Q_Random30'], m['Q_Cartesian30'], m['Q_Radial30']]).astype(np.uint8)
+    mid = (np.arange(B) % 3).astype(np.int32)
+    img, noise = S.batch(0, B)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('PNP_SLICE', mode)
+        with P.Engine(256, 256, Bmax=B) as eng:
+            eng.synthesize(img, noise, masks, mid)
+            assert eng.path_name == ('slice' if mode == '1' else 'fused')
+            y = eng.download_y()
+            eng.init_state()
+            eng.admm_cnc(6, 0.45, 0.5, 0.05, 64)
+            x = eng.x()
+            z, w = eng.get_state()
+            eng.init_state()
+            eng.admm_l1(5, 0.1, 0.015)
+            res[mode] = (x, z, w, eng.x())
+    for a, b in zip(res['1'], res['0']):
+        assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 2e-5
+    for b in sorted({0, B // 2, B - 1}):
+        y128 = y[b].astype(np.complex128)
+        assert rel_l2(res['1'][0][b], O.admm_cnc(y128, masks[mid[b]], 6)) <= 2e-6
+        assert rel_l2(res['1'][3][b], O.admm_l1(y128, masks[mid[b]], 5)) <= 2e-6
+
+
+def test_chip_filling_run_matches_the_two_launch_path(P, monkeypatch):
+    """512 slices x 50 CNC iterations (two rounds on every compute unit, the shape bench.py times): x, z, w of the
+    slice-resident kernel against the two-launch path on EVERY slice.  Both paths share the arithmetic cores but not
+    the data flow, so a store that lands wrong anywhere in the batch (buffer-store hazard) shows here:
+    the CNC map amplifies a wrong value, it does not hide it.  fp32 round-off between the two orders of operations
+    grows ~1.08x per iteration: measured max-abs 3e-5 after 50; a misplaced store is O(0.1)."""
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    m = S.reference_masks()
+    masks = np.stack([m['Q_Random30']]).astype(np.uint8)
+    B = 512
+    img, noise = S.batch(0, B)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('PNP_SLICE', mode)
+        with P.Engine(256, 256, Bmax=B) as eng:
+            eng.synthesize(img, noise, masks, np.zeros(B, np.int32))
+            eng.init_state()
+            eng.admm_cnc(50, 0.45, 0.5, 0.05, 64)
+            res[mode] = (eng.x(), *eng.get_state())
+    for name, a, b in zip('xzw', res['1'], res['0']):
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64)).reshape(B, -1).max(axis=1)
+        assert d.max() <= 1e-3, (name, int(d.argmax()), float(d.max()))
+        assert np.median(d) <= 1e-4, (name, float(np.median(d)))
