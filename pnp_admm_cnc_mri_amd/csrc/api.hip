@@ -79,6 +79,7 @@ struct pnp_ctx {
     Fused512* fused5 = nullptr;       // 512 x 512
     Slice256* slice = nullptr;        // 256 x 256 slice-resident loops (whole runs; pnp_dc_step stays on `fused`)
     bool slice_ready = false;
+    bool state_sliced = false;       // c->z / c->w are in the slice-resident kernel's order (slice_layout.h, sl_state_pos)
     int slice_min_b = 0;              // batches at least this large run their loops slice-resident
     bool slice_force = false;
     Fused256S<float>* fs32 = nullptr;   // 256 x 256 "split chain" engine in float (PNP_FUSED_COLS=2) ...
@@ -110,6 +111,18 @@ static ProxParams make_prox_cnc(double alpha, double lambda1, double reo, double
     return p;
 }
 static float dc_coeff(double reo) { return (float)(1.0 / (1.0 + 1.0 / 2.0 / reo)); }
+
+// The slice-resident loops keep z / w in their own order; everything else (the other kernel families, pnp_get_state /
+// pnp_set_state, pnp_init_state) sees natural [H][W].  One in-place kernel converts when the need changes.
+static int state_order(pnp_ctx* c, bool sliced) {
+    if (c->state_sliced == sliced) return PNP_OK;
+    if (c->B > 0) {
+        hipError_t e = slice256_state_order(c->stream, c->z, c->w, c->B, sliced);
+        if (e != hipSuccess) return fail(PNP_E_HIP, "state order: %s", hipGetErrorString(e));
+    }
+    c->state_sliced = sliced;
+    return PNP_OK;
+}
 
 static bool use_fused(pnp_ctx* c) { return c->fast && (c->fused || c->fused5 || c->fs32 || c->fs64) && c->fused_ready; }
 
@@ -339,6 +352,7 @@ static int prepare_fused_tables(pnp_ctx* c) {
 int pnp_upload_problem(pnp_ctx* c, const float* y, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
     CTX(c); F32_ONLY(c);
     if (!y) return fail(PNP_E_ARG, "pnp_upload_problem: y is null");
+    if (int rs = state_order(c, false)) return rs;      // under the OLD batch size, before it changes
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     rc = copy_in(c, c->y, y, (size_t)B * c->N * sizeof(float2), on_device);
@@ -350,6 +364,7 @@ int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int
                            const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
     CTX(c); F32_ONLY(c);
     if (!img || !noise) return fail(PNP_E_ARG, "pnp_synthesize_problem: img/noise is null");
+    if (int rs = state_order(c, false)) return rs;      // under the OLD batch size, before it changes
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     const size_t img_bytes = (size_t)B * c->N * sizeof(float);
@@ -399,6 +414,7 @@ int pnp_init_state(pnp_ctx* c) {
         c->have_x = false;
         return PNP_OK;
     }
+    c->state_sliced = false;                           // both arrays are rewritten below, in natural order
     ColArgs ca{};
     ca.in = c->y; ca.out = c->work; ca.B = c->B;
     HIPCHK(launch_cols(c->stream, c->H, c->W, false, MID_NONE, true, ca));
@@ -414,6 +430,8 @@ int pnp_set_state(pnp_ctx* c, const float* z, const float* w, int on_device) {
     CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(float);
     int rc;
+    if (z && w) c->state_sliced = false;               // both replaced: nothing to convert
+    else if ((rc = state_order(c, false))) return rc;
     if (z) { rc = copy_in(c, c->z, z, bytes, on_device); if (rc) return rc; }
     if (w) { rc = copy_in(c, c->w, w, bytes, on_device); if (rc) return rc; }
     c->have_x = false;
@@ -424,6 +442,7 @@ int pnp_get_state(pnp_ctx* c, float* z, float* w, int on_device) {
     CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(float);
     int rc;
+    if ((rc = state_order(c, false))) return rc;
     if (z) { rc = copy_out(c, z, c->z, bytes, on_device); if (rc) return rc; }
     if (w) { rc = copy_out(c, w, c->w, bytes, on_device); if (rc) return rc; }
     return PNP_OK;
@@ -474,6 +493,8 @@ static int run_loop_f64(pnp_ctx* c, int iters, bool cnc, const ProxParamsT<doubl
 static int run_loop(pnp_ctx* c, int iters, bool cnc, const ProxParams& pp, double reo) {
     if (iters < 0) return fail(PNP_E_ARG, "iters must be >= 0");
     if (!(reo > 0.0)) return fail(PNP_E_ARG, "reo must be > 0");
+    const bool slice_loop = iters > 0 && use_fused(c) && c->slice && c->slice_ready;
+    if (int rs = state_order(c, slice_loop)) return rs;
     if (iters == 0) {
         // the reference's loop body never runs and its x stays the initial x = |ifft2(y)| = z0 (S4:103, 107, 138)
         HIPCHK(hipMemcpyAsync(c->x, c->z, (size_t)c->B * c->N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));

@@ -322,6 +322,13 @@ template <typename R> PNP_HD cxT<R> blend_one(cxT<R> V, cxT<R> yh, int code, R c
     const R A = fma_(-ch, (R)code, (R)1);
     return mk<R>(fma_(A, V.x, c * yh.x), fma_(A, V.y, c * yh.y));
 }
+// blend_one for a field that arrives DOUBLED (V2 = 2 V; the slice-resident kernel's transposition leaves the 1/2 of the
+// real-to-complex unpack out): A/2 = fma(-ch/2, code, 1/2) is the exact half of blend_one's A and (A/2)(2V) = A V exactly
+// (powers of two commute with rounding), so the result is blend_one(V, ...) bit for bit.  chh = ch / 2 = c / 4.
+template <typename R> PNP_HD cxT<R> blend_one_doubled(cxT<R> V2, cxT<R> yh, int code, R c, R chh) {
+    const R A = fma_(-chh, (R)code, (R)0.5);
+    return mk<R>(fma_(A, V2.x, c * yh.x), fma_(A, V2.y, c * yh.y));
+}
 template <typename R> PNP_HD cxT<R> repack_p(cxT<R> xa, cxT<R> xb) { return mk<R>(xa.x - xb.y, xa.y + xb.x); }
 template <typename R> PNP_HD cxT<R> repack_q(cxT<R> xa, cxT<R> xb) { return mk<R>(xa.x + xb.y, xb.x - xa.y); }
 

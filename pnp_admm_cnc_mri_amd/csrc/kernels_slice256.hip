@@ -36,7 +36,7 @@
 #include <vector>
 
 #ifndef SLICE_PF
-#define SLICE_PF 2          // row pairs of z / w fetched ahead of a set's transforms (experiment knob)
+#define SLICE_PF 3          // of a set's 8 z / w accesses per lane: fetched ahead of the transforms (experiment knob)
 #endif
 
 namespace pnp {
@@ -54,8 +54,7 @@ struct SliceArgs {
     int first, B, iters;      // slices [first, first + B) of the arrays; iterations of this launch
     float scale, c;
     ProxCoef prox;
-    int stagger_ticks;        // experiment knob: start delay step (wall_clock64 ticks, 100 MHz), workgroup b waits (b & 3) steps
-    long long* prof;          // optional phase clock dump (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
+    long long* prof;          // phase clock dump of a -DSLICE_PROF build (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
 };
 
 // LDS geometry of the transforms.  Rows of RP = 18 complex (144 B): 16-byte aligned, so a lane reads its row by
@@ -140,6 +139,19 @@ __device__ __forceinline__ float dpp_lane_xor1(float v) {
 }
 __device__ __forceinline__ c32 dpp_lane_xor1(c32 v) { return mk<float>(dpp_lane_xor1(v.x), dpp_lane_xor1(v.y)); }
 
+// own.x - (partner lane's own.y) and own.y + (partner lane's own.x) as ONE DPP instruction each (hipcc otherwise builds the
+// partner's value with two v_mov_dpp and a packed add: three instructions per value)
+__device__ __forceinline__ float sub_partner(float a, float b) {          // a - dpp(b)
+    float r;
+    asm("v_subrev_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float add_partner(float a, float b) {          // a + dpp(b)
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+
 // The packed-fp32 transform core (f2, addsub_rot, rot2, tmul_v, tmul_s, dft16_pk) lives in fft16.h: every float kernel uses it.
 
 // 16-lane FFT-256 on a[16] (lane t holds index t + 16 j), exchange through the group's region
@@ -184,26 +196,29 @@ __device__ __forceinline__ void group_fft256(c32 (&ac)[16], const c32* twl, c32*
 }
 
 // ------------------------------------------------------------------------------------------
-// rows: one register set = the share of 4 row pairs (8 image rows) this wave owns.
+// rows: one register set = the share of 4 row pairs (8 image rows) this wave owns; lane (g, t) holds elements
+// t + 16 j of row pair 32 set + 4 wave + g.  z / w are stored in HBM in the SAME order (sl_state_pos, slice_layout.h):
+// the lane's q-th 16-byte access of a row pair is (row 2r, row 2r + 1) x (j = 2q, 2q + 1) = the register pairs
+// a[2q], a[2q + 1], so the whole z- / w-update runs on the transform's registers.  (Until round 3 the state was in
+// natural order and every set went through LDS twice to meet it; that was a third of the kernel's LDS traffic.)
 // The z / w values of a set are FETCHED AHEAD (issued before the previous set's forward transform,
 // consumed after this set's inverse transform), so HBM latency hides behind the wave's own FFT work.
 // ------------------------------------------------------------------------------------------
-struct RowLoads {              // [row pair of the set][4 consecutive pixels]; a = image row 2rr, b = row 2rr + 1
-    float za[4][4], wa[4][4], zb[4][4], wb[4][4];
+struct RowLoads {              // [q][(j & 1) * 2 + sel]
+    float z[8][4], w[8][4];
 };
+__device__ __forceinline__ int row_set_offset(int set, int wv) { return (32 * set + 4 * wv) * 2048; }     // bytes; wave-uniform
 
-template <int PROX, bool HAS_INV, int I0, int I1>
-__device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L, int set, int wv, int lane) {
-    const int voff = 16 * lane;
+// voff = 2048 g + 16 t (bytes inside the wave's 8 KiB of a set); the q-th access adds 256 q as an instruction offset
+template <int PROX, bool HAS_INV, int Q0, int Q1>
+__device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L, int soff, int voff, int qbase = 0) {
 #pragma unroll
-    for (int i = I0; i < I1; ++i) {
-        const int soff = (2 * (32 * set + 4 * wv + i)) * 1024;            // wave-uniform byte offset of image row 2rr
+    for (int q = qbase + Q0; q < qbase + Q1; ++q) {
         if (PROX == 3) {                                                   // single-state ADMM_L1: only the w buffer (it carries u)
-            ld4(b.w, voff, soff, L.wa[i]);
-            ld4(b.w, voff, soff + 1024, L.wb[i]);
+            ld4(b.w, voff + 256 * q, soff, L.w[q]);
         } else if (PROX != 0 || !HAS_INV) {
-            ld4(b.z, voff, soff, L.za[i]); ld4(b.w, voff, soff, L.wa[i]);
-            ld4(b.z, voff, soff + 1024, L.zb[i]); ld4(b.w, voff, soff + 1024, L.wb[i]);
+            ld4(b.z, voff + 256 * q, soff, L.z[q]);
+            ld4(b.w, voff + 256 * q, soff, L.w[q]);
         }
     }
 }
@@ -215,7 +230,8 @@ __device__ __forceinline__ f2 clamp2(f2 a, float c) {
 }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return k2(v, v); }
-// z / w updates of TWO neighbouring pixels of one image row (prox_l1_pt / prox_cnc_pt of fft16.h, same operation order)
+// z / w updates of TWO pixels -- the same column of image rows 2r and 2r + 1 (prox_l1_pt / prox_cnc_pt of fft16.h, same
+// operation order per pixel)
 template <int PROX>
 __device__ __forceinline__ void prox_pair(f2 x, f2& z, f2& w, const ProxCoef& pc) {
     const f2 u = x + w;
@@ -229,64 +245,72 @@ __device__ __forceinline__ void prox_pair(f2 x, f2& z, f2& w, const ProxCoef& pc
     w = u - z;
 }
 
-// Pointwise phase of ONE row pair for 4 consecutive pixels per lane; the arithmetic of pointwise4
-// (fused_pointwise.h) with re = image row 2rr and im = row 2rr + 1 of the same slice.
-// cell: the 4 complex LDS values (x in, v out); voff = 16 lane; soff = byte offset of row 2rr in the slice.
-// `last` (wave-uniform, run time): the final iteration of a launch stores z, w AND x; the loop has ONE row-phase body
-// for all its iterations (the kernel is 100+ KB of code and the instruction cache 64 KB), at the price of one
-// unused forward transform per launch.
-// Pixels are paired (q, q + 1) WITHIN an image row: the 16-byte loads / stores are two aligned register pairs each, so
-// the packed instructions need no moves (pairing row a with row b, as hipcc does by itself, costs two per pair and array).
+// Pointwise phase of one 16-byte access: the lane's registers a0 = a[2q], a1 = a[2q + 1] (re = image row 2r, im = row 2r + 1)
+// with their z / w values; the arithmetic of pointwise4 (fused_pointwise.h).  vs = byte offset of the access in the slice.
+// `last` (wave-uniform, run time): the final iteration of a launch stores z and w also in ADMM_L1's single-state form;
+// the loop has ONE row-phase body for all its iterations (the kernel is 80+ KB of code and the instruction cache 64 KB;
+// a second instance for the final iteration spills 350-490 bytes per lane), at the price of one unused forward
+// transform per launch.
 template <bool HAS_INV, int PROX, bool HAS_FWD>
-__device__ __forceinline__ void pointwise_rowpair(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32* cell,
-                                                  int voff, int soff, float (&za_)[4], float (&wa_)[4], float (&zb_)[4], float (&wb_)[4]) {
-    const int soffb = soff + 1024;
-    f2 za[2] = {k2(za_[0], za_[1]), k2(za_[2], za_[3])}, wa[2] = {k2(wa_[0], wa_[1]), k2(wa_[2], wa_[3])};
-    f2 zb[2] = {k2(zb_[0], zb_[1]), k2(zb_[2], zb_[3])}, wb[2] = {k2(wb_[0], wb_[1]), k2(wb_[2], wb_[3])};
-    f2 xa[2] = {splat(0.f), splat(0.f)}, xb[2] = {splat(0.f), splat(0.f)};
+__device__ __forceinline__ void pointwise_q(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last,
+                                            c32& a0, c32& a1, const float (&z_)[4], const float (&w_)[4], int vs) {
+    f2 z[2] = {k2(z_[0], z_[1]), k2(z_[2], z_[3])}, w[2] = {k2(w_[0], w_[1]), k2(w_[2], w_[3])};
+    f2 x[2] = {splat(0.f), splat(0.f)};
     if (HAS_INV) {
-        const float4 c01 = *reinterpret_cast<const float4*>(cell);
-        const float4 c23 = *reinterpret_cast<const float4*>(cell + 2);
-        xa[0] = k2(fabsf(c01.x) * scale, fabsf(c01.z) * scale); xb[0] = k2(fabsf(c01.y) * scale, fabsf(c01.w) * scale);
-        xa[1] = k2(fabsf(c23.x) * scale, fabsf(c23.z) * scale); xb[1] = k2(fabsf(c23.y) * scale, fabsf(c23.w) * scale);
+        x[0] = k2(fabsf(a0.x) * scale, fabsf(a0.y) * scale);
+        x[1] = k2(fabsf(a1.x) * scale, fabsf(a1.y) * scale);
     }
-#define SL_ST4(buf, so, v) { const float q_[4] = {v[0].x, v[0].y, v[1].x, v[1].y}; st4(buf, voff, so, q_); }
+#define SL_ST4(buf, v) { const float q_[4] = {v[0].x, v[0].y, v[1].x, v[1].y}; st4(buf, vs, 0, q_); }
     if (PROX == 3) {                                   // ADMM_L1 single-state form: the w buffer carries u = x + w_old
-        f2 ua[2], ub[2];
+        f2 u[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (!u_first) {
-                wa[q] = wa[q] - (wa[q] - clamp2(wa[q], pc.thr));
-                wb[q] = wb[q] - (wb[q] - clamp2(wb[q], pc.thr));
-            }
-            ua[q] = xa[q] + wa[q];
-            ub[q] = xb[q] + wb[q];
-            za[q] = ua[q] - clamp2(ua[q], pc.thr); wa[q] = ua[q] - za[q];
-            zb[q] = ub[q] - clamp2(ub[q], pc.thr); wb[q] = ub[q] - zb[q];
+        for (int jj = 0; jj < 2; ++jj) {
+            if (!u_first) w[jj] = w[jj] - (w[jj] - clamp2(w[jj], pc.thr));
+            u[jj] = x[jj] + w[jj];
+            z[jj] = u[jj] - clamp2(u[jj], pc.thr);
+            w[jj] = u[jj] - z[jj];
         }
         if (!last) {
-            SL_ST4(b.w, soff, ua);
-            SL_ST4(b.w, soffb, ub);
+            SL_ST4(b.w, u);
         } else {
-            SL_ST4(b.z, soff, za); SL_ST4(b.w, soff, wa);
-            SL_ST4(b.z, soffb, zb); SL_ST4(b.w, soffb, wb);
+            SL_ST4(b.z, z);
+            SL_ST4(b.w, w);
         }
     }
     if (PROX == 1 || PROX == 2) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { prox_pair<PROX>(xa[q], za[q], wa[q], pc); prox_pair<PROX>(xb[q], zb[q], wb[q], pc); }
-        SL_ST4(b.z, soff, za); SL_ST4(b.w, soff, wa);
-        SL_ST4(b.z, soffb, zb); SL_ST4(b.w, soffb, wb);
-    }
-    if (HAS_INV && last) {
-        SL_ST4(b.x, soff, xa);
-        SL_ST4(b.x, soffb, xb);
+        for (int jj = 0; jj < 2; ++jj) prox_pair<PROX>(x[jj], z[jj], w[jj], pc);
+        SL_ST4(b.z, z);
+        SL_ST4(b.w, w);
     }
 #undef SL_ST4
     if (HAS_FWD) {
-        *reinterpret_cast<float4*>(cell) = make_float4(za[0].x - wa[0].x, zb[0].x - wb[0].x, za[0].y - wa[0].y, zb[0].y - wb[0].y);
-        *reinterpret_cast<float4*>(cell + 2) = make_float4(za[1].x - wa[1].x, zb[1].x - wb[1].x, za[1].y - wa[1].y, zb[1].y - wb[1].y);
+        const f2 v0 = z[0] - w[0], v1 = z[1] - w[1];
+        a0 = from2(v0);
+        a1 = from2(v1);
     }
+}
+
+// x of the last iteration leaves in NATURAL order (it is the caller's result): the set's x = |re|, |im| / N goes through
+// the wave's four exchange regions once -- region g holds row pair g of the set as 256 complex (row 2r, row 2r + 1) -- and
+// every lane stores 4 consecutive pixels of both rows of each pair.  Once per launch.
+__device__ __forceinline__ void store_x_natural(const SliceBufs& b, float scale, const c32 (&a)[16], c32* wreg, int set, int wv, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    c32* region = wreg + g * REGION;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) region[t + 16 * j] = mk<float>(fabsf(a[j].x) * scale, fabsf(a[j].y) * scale);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const c32* cell = wreg + i * REGION + 4 * lane;
+        const float4 c01 = *reinterpret_cast<const float4*>(cell);
+        const float4 c23 = *reinterpret_cast<const float4*>(cell + 2);
+        const int vs = 16 * lane + (2 * (32 * set + 4 * wv + i)) * 1024;
+        const float xa[4] = {c01.x, c01.z, c23.x, c23.z}, xb[4] = {c01.y, c01.w, c23.y, c23.w};
+        st4(b.x, vs, 0, xa);
+        st4(b.x, vs + 1024, 0, xb);
+    }
+    wave_sync();
 }
 
 // all four register sets of a wave; loads of set s + 1 are in flight during the transforms around them
@@ -295,35 +319,34 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
                                           c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
-    // PF row pairs of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
-    constexpr int PF = (PROX == 3) ? 4 : SLICE_PF;
+    const int voff = 2048 * g + 16 * t;
+    // PF accesses of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
+    constexpr int PF = (PROX == 3) ? 8 : SLICE_PF;
     RowLoads L;
-    issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, 0, wv, lane);
+    issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, row_set_offset(0, wv), voff);
 #pragma unroll
     for (int set = 0; set < SL_SETS; ++set) {
         c32 (&a)[16] = F[set];
+        const int soff = row_set_offset(set, wv);
         if (HAS_INV) {
 #ifndef SLICE_ABLATE_ROWFFT
             group_fft256<true>(a, twl, region, t);
 #endif
-#pragma unroll
-            for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];       // natural order: element n of row pair g
-            wave_sync();
         }
-        issue_row_loads<PROX, HAS_INV, PF, 4>(b, L, set, wv, lane);
-        // the wave's 4 row pairs: 4 consecutive pixels per lane, one full 1-KiB image row per access
+        if (HAS_INV && last) store_x_natural(b, scale, a, wreg, set, wv, lane);
+        const int vs = voff + soff;
+        // rolling fetch: access q + PF goes out when access q is consumed (PF accesses = 8 PF registers in flight; all 8 at
+        // once, on top of the 128 data registers, made hipcc spill)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int soff = (2 * (32 * set + 4 * wv + i)) * 1024;
-            pointwise_rowpair<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, wreg + i * REGION + 4 * lane, 16 * lane, soff,
-                                                               L.za[i], L.wa[i], L.zb[i], L.wb[i]);
+        for (int q = 0; q < 8; ++q) {
+            if (q + PF < 8) issue_row_loads<PROX, HAS_INV, 0, 1>(b, L, soff, voff, q + PF);
+            pointwise_q<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, a[2 * q], a[2 * q + 1], L.z[q], L.w[q], vs + 256 * q);
+#ifdef SLICE_PW_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
-        if (set + 1 < SL_SETS) issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, set + 1, wv, lane);
+        if (set + 1 < SL_SETS) issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, row_set_offset(set + 1, wv), voff);
         if (HAS_FWD) {
-            wave_sync();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = region[t + 16 * j];
-            wave_sync();
 #ifndef SLICE_ABLATE_ROWFFT
             group_fft256<false>(a, twl, region, t);
 #endif
@@ -347,17 +370,29 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
     X(8, 12, ((t) ? SL_M + 64 - (t) : SL_M))                                                      \
     X(9, 9, SL_M + 48 - (t)) X(10, 10, SL_M + 32 - (t)) X(11, 11, SL_M + 16 - (t))
 
+// The MIRROR half of a buffer row (slots SL_M ..) holds its values with re and im SWAPPED.  Both lanes of a pair then run
+// the same two instructions in both transpositions (no selects by lane parity): with own = the lane's value as stored and
+// (.)' = the partner lane's, T1 needs ((own.x + own.y'), (own.y - own.x')) / 2 and T2 writes (own.x - own.y', own.y + own.x').
+// The swap itself is free: a swapped 8-byte access is a ds_write2_b32 / ds_read2_b32 with its two dword offsets exchanged.
+__device__ __forceinline__ void lds_put(c32* p, c32 v, bool swapped) {
+    float* f = reinterpret_cast<float*>(p);
+    if (swapped) { f[0] = v.y; f[1] = v.x; } else { *p = v; }
+}
+__device__ __forceinline__ c32 lds_get(const c32* p, bool swapped) {
+    const float* f = reinterpret_cast<const float*>(p);
+    return swapped ? mk<float>(f[1], f[0]) : *p;
+}
 // row-form registers of one set -> buffer row `rp`
 template <int P>
 __device__ __forceinline__ void t_store_rows(const c32 (&F)[16], c32* rp, int t) {
-#define SL_T1_STORE(ja, jb, slot) { rp[slot] = t ? F[ja] : F[jb]; }
+#define SL_T1_STORE(ja, jb, slot) { lds_put(rp + (slot), t ? F[ja] : F[jb], (ja) >= 8); }
     if (P == 0) { SL_PASS0_REGS(SL_T1_STORE, t) } else { SL_PASS1_REGS(SL_T1_STORE, t) }
 #undef SL_T1_STORE
 }
 // buffer row `rp` -> row-form registers of one set (lane 0 of a group is fixed up after pass 1)
 template <int P>
 __device__ __forceinline__ void t_load_rows(c32 (&F)[16], const c32* rp, int t) {
-#define SL_T2_LOAD(ja, jb, slot) { F[ja] = rp[slot]; }
+#define SL_T2_LOAD(ja, jb, slot) { F[ja] = lds_get(rp + (slot), (ja) >= 8); }
     if (P == 0) { SL_PASS0_REGS(SL_T2_LOAD, t) } else { SL_PASS1_REGS(SL_T2_LOAD, t) }
 #undef SL_T2_LOAD
     if (P == 1) {         // lane 0 received k = 128 in register 12 (pass 0) and k = 192 in register 8 (pass 1): swap them
@@ -369,10 +404,12 @@ __device__ __forceinline__ void t_load_rows(c32 (&F)[16], const c32* rp, int t) 
 
 // T1 read side.  (d, m) = (C_r[c], C_r[-c]) of a row pair give the row transforms of its two REAL image rows at column c:
 //   even lane: unpack_a(d, m) = (d + conj m) / 2,   odd lane: unpack_b(d, m) = (d - conj m) / (2 i)     (fft16.h).
-// The even lane of a pair reads d, the odd lane m -- ONE 8-byte LDS read per lane and value (a lane reading both makes
-// hipcc emit ds_read2_b64, which moves 16 bytes per lane at half the LDS rate) -- and the partner's value comes by DPP:
-//   own = (even ? d : m), other = partner's own;   p = odd ? own.y : own.x,  q = odd ? own.x : own.y
-//   value = ( p + partner's q,  q - partner's p ) / 2      -- the sums and differences of unpack_a / unpack_b, term for term
+// The even lane of a pair reads d, the odd lane m with its halves swapped (see above) -- ONE 8-byte LDS read per lane and
+// value -- and the partner's halves come by DPP inside the add / subtract:
+//   2 x value = ( own.x + partner's own.y,  own.y - partner's own.x )     -- the sums and differences of unpack_a / unpack_b, term for term;
+//   the column phase works on the doubled field and takes the 1/2 back in its blend coefficient (exactly: a power of two)
+// The 16 reads of a column go out in two groups of 8 (until round 3 every read was waited for on its own: 64 serial LDS
+// round trips per wave and iteration).
 template <int P>
 __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL_SETS][16], c32* buf, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
@@ -385,17 +422,22 @@ __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL
         const bool packed = (P == 0 && h == 0 && cc == 0);
         const c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const c32 own = col[8 * j * SL_P];
-            const float pp = odd ? own.y : own.x, qq = odd ? own.x : own.y;
-            const float dq = dpp_lane_xor1(qq), dp = dpp_lane_xor1(pp);
-            c32 v = mk<float>(0.5f * (pp + dq), 0.5f * (qq - dp));
-            if (P == 0 && h == 0) {                     // the packed column c = 0 takes the raw values: (C[0], C[128]) -> re / im parts
-                const c32 raw = mk<float>(odd ? dq : pp, odd ? pp : dq);
-                v = packed ? raw : v;
+        for (int jb = 0; jb < 16; jb += 8) {
+            c32 own[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) own[k] = col[8 * (jb + k) * SL_P];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // TWICE the unpacked value: the 1/2 is folded into the blend coefficient (blend_one_doubled, exact)
+                c32 v = mk<float>(add_partner(own[k].x, own[k].y), sub_partner(own[k].y, own[k].x));
+                if (P == 0 && h == 0) {                 // the packed column c = 0 takes the raw values: (C[0], C[128]) -> re / im parts
+                    const float oy = dpp_lane_xor1(own[k].y);
+                    const c32 raw = mk<float>(odd ? oy : own[k].x, odd ? own[k].x : oy);
+                    v = packed ? raw : v;
+                }
+                G[2 * P + h][jb + k] = v;
+                pin(G[2 * P + h][jb + k]);              // unpack as the values arrive: raw values must not pile up across the barrier
             }
-            G[2 * P + h][j] = v;
-            pin(G[2 * P + h][j]);                       // unpack as the values arrive: raw values must not pile up across the barrier
         }
     }
     __syncthreads();
@@ -412,14 +454,13 @@ __device__ __forceinline__ void t2_pass(const c32 (&G)[SL_SETS][16], c32 (&F)[SL
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             // the lane pair (even, odd) holds (ue, uo) = column values of image rows 2r, 2r + 1; the even lane writes
-            // repack_p(ue, uo) = ue + i uo, the odd lane repack_q(ue, uo) = conj ue + i conj uo.  In terms of the lane's own
-            // value and its partner's:  A = own.x - other.y,  B = own.y + other.x  ->  even (A, B), odd (B, A)
+            // repack_p(ue, uo) = ue + i uo to the direct slot, the odd lane repack_q(ue, uo) = conj ue + i conj uo to the mirror
+            // slot -- with its halves swapped, which makes both lanes' values ( own.x - partner's own.y,  own.y + partner's own.x )
             const c32 own = G[2 * P + h][j];
-            const c32 other = dpp_lane_xor1(own);
-            const float A = own.x - other.y, Bv = own.y + other.x;
-            c32 v = mk<float>(odd ? Bv : A, odd ? A : Bv);
-            if (P == 0 && h == 0) {                     // packed column: (ue.x, uo.x) / (ue.y, uo.y)
-                const c32 raw = mk<float>(odd ? other.y : own.x, odd ? own.y : other.x);
+            c32 v = mk<float>(sub_partner(own.x, own.y), add_partner(own.y, own.x));
+            if (P == 0 && h == 0) {                     // packed column: (ue.x, uo.x) direct, (ue.y, uo.y) mirror (stored swapped)
+                const c32 other = dpp_lane_xor1(own);
+                const c32 raw = mk<float>(odd ? own.y : own.x, odd ? other.y : other.x);
                 v = packed ? raw : v;
             }
             col[8 * j * SL_P] = v;
@@ -439,10 +480,14 @@ struct ColLoads {
     uint32_t code;
 };
 __device__ __forceinline__ void issue_col_loads(const SliceBufs& b, ColLoads& Y, int set, int wv, int lane) {
-    const int ybase = ((set * 16) * 8 + wv) * 64 * 8;              // yh3_index(.., set, j = 0, wv, lane = 0) in bytes; + j * 4096
+    const int ybase = (set * 8 + wv) * 8192;                       // the wave's 8 KiB block of the set: yh3_index(.., set, j = 0, wv, lane = 0) in bytes
     Y.code = __builtin_amdgcn_raw_buffer_load_b32(b.mh, 4 * lane, (set * 8 + wv) * 64 * 4, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) Y.yh[j] = ldc(b.yh, 8 * lane, ybase + j * 4096);
+    for (int jp = 0; jp < 8; ++jp) {                               // (j = 2 jp, 2 jp + 1) per 16-byte access; offsets 0 .. 3072 are instruction immediates
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(b.yh, 16 * lane + 1024 * (jp & 3), ybase + 4096 * (jp >> 2), 0);
+        Y.yh[2 * jp] = mk<float>(__uint_as_float(q.x), __uint_as_float(q.y));
+        Y.yh[2 * jp + 1] = mk<float>(__uint_as_float(q.z), __uint_as_float(q.w));
+    }
 }
 
 __device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G)[SL_SETS][16], c32* wreg, c32* ysl, const c32* twl, int wv, int lane) {
@@ -479,7 +524,7 @@ __device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G
             wave_sync();
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = blend_one(a[j], Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, ch);
+            for (int j = 0; j < 16; ++j) a[j] = blend_one_doubled(a[j], Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, 0.5f * ch);
         }
         if (set + 1 < SL_SETS) issue_col_loads(b, Y, set + 1, wv, lane);
         group_fft256<true>(a, twl, region, t);                    // column c of the blended field, unnormalised
@@ -497,12 +542,6 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     c32* twl = lds + SL_BUF;
     if (tid < 256) twl[RP * (tid >> 4) + (tid & 15)] = g_tws[((tid >> 4) * (tid & 15)) & 255];     // [t][k] = W256^(t k), rows of RP
     c32* wreg = lds + wv * WREG;
-    if (p.stagger_ticks > 0) {
-        // experiment knob (PNP_SLICE_STAGGER_US, default off): equal workgroups started together run their HBM-heavy
-        // row phases together, chip-wide; a one-time start offset per residue class spreads them (measured: no effect)
-        const long long t0 = wall_clock64(), wait = (long long)(blockIdx.x & 3) * p.stagger_ticks;
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     __syncthreads();
     for (int sb = blockIdx.x; sb < p.B; sb += gridDim.x) {
         const int slice = p.first + sb;
@@ -512,27 +551,34 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
         b.yh = make_rsrc(p.Yh + (size_t)slice * YH3_SLICE, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
         b.ys = make_rsrc(p.Ys + (size_t)slice * 256, 256 * 8); b.ms = make_rsrc(p.Ms + (size_t)slice * 16, 16 * 4);
         c32 F[SL_SETS][16];
+        // phase clocks exist only in a -DSLICE_PROF build (profiles/variants.sh): in the product they cost two registers
+        // and a dozen branches of a kernel that has neither to spare
+#ifdef SLICE_PROF
         long long* prof = (p.prof && tid == 0 && sb == (int)blockIdx.x) ? p.prof + (size_t)slice * (2 + 6 * p.iters) : nullptr;
-        if (prof) *prof++ = wall_clock64();
+#define SL_STAMP() if (prof) *prof++ = wall_clock64()
+#else
+#define SL_STAMP()
+#endif
+        SL_STAMP();
         row_phase<false, 0, true>(b, p.prox, p.scale, 1, false, F, wreg, twl, wv, opaque(lane));
-        if (prof) *prof++ = wall_clock64();
+        SL_STAMP();
         for (int it = 0; it < p.iters; ++it) {
             c32 G[SL_SETS][16];
             __syncthreads();                      // every wave is done with its private region: the buffer aliases them
-            if (prof) *prof++ = wall_clock64();   // wave 0's wait for the slowest wave of the row phase ends here
+            SL_STAMP();                           // wave 0's wait for the slowest wave of the row phase ends here
             t1_pass<0>(F, G, lds, wv, opaque(lane));
             t1_pass<1>(F, G, lds, wv, opaque(lane));
-            if (prof) *prof++ = wall_clock64();
+            SL_STAMP();
             col_phase(b, p.c, G, wreg, lds + SL_YS, twl, wv, opaque(lane));
-            if (prof) *prof++ = wall_clock64();
+            SL_STAMP();
             __syncthreads();
-            if (prof) *prof++ = wall_clock64();
+            SL_STAMP();
             t2_pass<0>(G, F, lds, wv, opaque(lane));
             t2_pass<1>(G, F, lds, wv, opaque(lane));
-            if (prof) *prof++ = wall_clock64();
+            SL_STAMP();
             const int u_first = (it == 0);
             row_phase<true, PROX, true>(b, p.prox, p.scale, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane));
-            if (prof) *prof++ = wall_clock64();
+            SL_STAMP();
         }
         __syncthreads();
     }
@@ -562,6 +608,44 @@ __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* m
         if (k2 < 128) Mh[mh3_index(slice, set, wv, 16 * (c & 3) + k1)] = v;
         else          Ms[slice * 16 + k1] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// natural order <-> slice order of the state arrays (sl_state_pos), in place: one block per (row pair, slice), 128
+// threads x 16 bytes per array.  Runs when a context's loops switch kernel families or the caller reads / writes the state.
+// ------------------------------------------------------------------------------------------
+template <bool TO_SLICE>
+__global__ __launch_bounds__(128) void k_state_order(float* z, float* w) {
+    __shared__ float tile[2][512];
+    const int i = threadIdx.x, sel = i >> 6, n0 = 4 * (i & 63);
+    const size_t base = ((size_t)blockIdx.y * 128 + blockIdx.x) * 512;
+    float4* pz = reinterpret_cast<float4*>(z + base);
+    float4* pw = reinterpret_cast<float4*>(w + base);
+    const float4 vz = pz[i], vw = pw[i];
+    const float az[4] = {vz.x, vz.y, vz.z, vz.w}, aw[4] = {vw.x, vw.y, vw.z, vw.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int at = TO_SLICE ? sl_state_pos(sel, n0 + k) : 4 * i + k;
+        tile[0][at] = az[k];
+        tile[1][at] = aw[k];
+    }
+    __syncthreads();
+    float oz[4], ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int at = TO_SLICE ? 4 * i + k : sl_state_pos(sel, n0 + k);
+        oz[k] = tile[0][at];
+        ow[k] = tile[1][at];
+    }
+    pz[i] = make_float4(oz[0], oz[1], oz[2], oz[3]);
+    pw[i] = make_float4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+hipError_t slice256_state_order(hipStream_t s, float* z, float* w, int B, bool to_slice) {
+    if (B <= 0) return hipSuccess;
+    if (to_slice) hipLaunchKernelGGL(k_state_order<true>, dim3(128, B), dim3(128), 0, s, z, w);
+    else          hipLaunchKernelGGL(k_state_order<false>, dim3(128, B), dim3(128), 0, s, z, w);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -657,7 +741,6 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
     a.prof = nullptr;
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    a.stagger_ticks = env_int("PNP_SLICE_STAGGER_US", 0) * 100;          // experiment knob (measured: no effect)
     const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
     int queues = env_int("PNP_SLICE_QUEUES", 1), seg_len = env_int("PNP_SLICE_SEGMENT", 0);   // measured: 1 launch is best
     if (queues < 1) queues = 1;
@@ -667,7 +750,11 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     if (segments < 1) segments = 1;
 
     long long* d_prof = nullptr;
-    const char* prof_path = getenv("PNP_SLICE_PROF");          // debugging aid: per-phase clocks of each workgroup (single launch only)
+#ifdef SLICE_PROF
+    const char* prof_path = getenv("PNP_SLICE_PROF");          // -DSLICE_PROF builds: per-phase clocks of each workgroup (single launch only)
+#else
+    const char* prof_path = nullptr;
+#endif
     const size_t prof_n = (size_t)B * (2 + 6 * (size_t)iters);
     if (prof_path) {
         queues = 1; segments = 1;

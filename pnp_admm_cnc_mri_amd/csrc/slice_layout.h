@@ -47,15 +47,27 @@ constexpr int SL_WAVES = 8, SL_SETS = 4;
 PNP_HD int sl_unit(int set, int wv, int lane) { return 32 * set + 4 * wv + (lane >> 4); }     // r or c
 
 // per-slice operand tables in column-form thread order
-//   Yh3 : [slice][set 4][j 16][wave 8][lane 64] complex   Yh at (k1 = t + 16 j, k2 = c); for c = 0: k2 = 0
+//   Yh3 : [slice][set 4][wave 8][j/2 8][lane 64][j%2] complex   Yh at (k1 = t + 16 j, k2 = c); for c = 0: k2 = 0.
+//         A wave's operands of a set are ONE contiguous 8 KiB block read by eight 16-byte-per-lane accesses (two j each)
 //   Mh3 : [slice][set 4][wave 8][lane 64] u32, 2 bits per j = 2 Mh
 //   Ys3 : [slice][256] complex, Ms3 : [slice][16] u32 -- the same for k2 = 128 (second half of c = 0), lane t, bits j
 constexpr size_t YH3_SLICE = 4 * 16 * 8 * 64;
 constexpr size_t MH3_SLICE = 4 * 8 * 64;
 PNP_HD size_t yh3_index(int slice, int set, int j, int wv, int lane) {
-    return (size_t)slice * YH3_SLICE + ((((size_t)set * 16 + j) * 8 + wv) * 64 + lane);
+    return (size_t)slice * YH3_SLICE + ((((size_t)set * 8 + wv) * 8 + (j >> 1)) * 64 + lane) * 2 + (j & 1);
 }
 PNP_HD size_t mh3_index(int slice, int set, int wv, int lane) { return (size_t)slice * MH3_SLICE + (((size_t)set * 8 + wv) * 64 + lane); }
+
+// State arrays (z, w) of a slice-resident run live in HBM in "slice order": rows stay where they are, but the 512 values
+// of a ROW PAIR r (image rows 2r, 2r + 1 = re / im of the packed complex row) are stored in the thread order of the row
+// transform, so that the z-/w-update works on the transform's own registers (no natural-order staging through LDS) and
+// every access is still a full 16-byte lane access of a 256-byte contiguous run per 16-lane group:
+//   pixel n = t + 16 j of row 2r + sel  ->  float index  512 r + 64 (j >> 1) + 4 t + 2 (j & 1) + sel
+// i.e. lane t's q-th 16-byte access (q = 0..7) holds (row 2r, row 2r+1) x (j = 2q, 2q + 1) = its registers a[2q], a[2q + 1].
+// pnp_get_state / pnp_set_state / the other kernel families see the natural [256][256] order: api.hip converts in place
+// (k_state_order) when a run switches families.  x is always natural.
+PNP_HD int sl_state_pos(int sel, int n) { return 64 * (n >> 5) + 4 * (n & 15) + 2 * ((n >> 4) & 1) + sel; }     // within the row pair's 512 floats
+PNP_HD size_t sl_state_index(int row, int n) { return (size_t)(row >> 1) * 512 + sl_state_pos(row & 1, n); }     // within the slice's 65536 floats
 
 // the packed column c = 0 after its transform: G[k1] = A[k1] + i B[k1] with A, B the transforms of the
 // REAL columns k2 = 0 and k2 = 128:  A = unpack_a(G[k1], G[-k1]),  B = unpack_b(G[k1], G[-k1]),

@@ -3,6 +3,8 @@
 // the two-pass LDS transposition buffer, the per-slice operand tables in thread order, the packed
 // column c = 0.  One slice, one ADMM iteration from (z, w):  rows(first) -> T1 -> columns -> T2 ->
 // rows(last, prox).  Input file as fused_emulation.cpp (slice 0 of it is used); output x, z, w (double).
+// z / w go through the kernel's HBM order of the state (sl_state_index): the emulation converts the natural-order input
+// first and reads / writes every value where the kernel's lane finds it.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,12 +70,29 @@ int main(int argc, char** argv) {
         Ys[t + 16 * j] = yh;
         Ms[t] |= (uint32_t)code << (2 * j);
     }
+    // ---- state arrays in slice order (what api.hip's k_state_order leaves in HBM) ----------------
+    std::vector<float> zs(N), ws(N);
+    {
+        std::vector<char> hit(N, 0);
+        for (int row = 0; row < 256; ++row) for (int n = 0; n < 256; ++n) {
+            const size_t at = sl_state_index(row, n);
+            if (at >= (size_t)N || hit[at]) return 15;                            // the order is a permutation of the slice
+            hit[at] = 1;
+            zs[at] = z[row * 256 + n];
+            ws[at] = w[row * 256 + n];
+        }
+    }
+    // the lane's q-th 16-byte access of row pair r: floats 512 r + 64 q + 4 t .. + 3 = (row 2r, row 2r+1) x (j = 2q, 2q + 1)
+    auto lane_access = [](int r, int t, int q, int k) { return (size_t)512 * r + 64 * q + 4 * t + k; };
+    for (int r = 0; r < 128; ++r) for (int t = 0; t < 16; ++t) for (int q = 0; q < 8; ++q) for (int k = 0; k < 4; ++k)
+        if (lane_access(r, t, q, k) != sl_state_index(2 * r + (k & 1), t + 16 * (2 * q + (k >> 1)))) return 16;
     // ---- rows (first): F <- row transforms of the row pairs ------------------------------------
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
         const int r = sl_unit(set, wv, lane), t = lane & 15;
         for (int j = 0; j < 16; ++j) {
             const int n = t + 16 * j;
-            F[wv][lane][set][j] = mk<R>(z[(2 * r) * 256 + n] - w[(2 * r) * 256 + n], z[(2 * r + 1) * 256 + n] - w[(2 * r + 1) * 256 + n]);
+            const size_t ia = sl_state_index(2 * r, n), ib = sl_state_index(2 * r + 1, n);
+            F[wv][lane][set][j] = mk<R>(zs[ia] - ws[ia], zs[ib] - ws[ib]);
         }
     }
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < SL_SETS; ++set) group_fft(wv, g, set, false);
@@ -88,28 +107,29 @@ int main(int argc, char** argv) {
                 const int k = t + 16 * j;
                 if (sl_pass(k) != p) continue;
                 if (!std::isnan(LDS[r * SL_P + sl_slot(k)].x)) return 6;          // slots must not collide
-                LDS[r * SL_P + sl_slot(k)] = F[wv][lane][set][j];
+                const C f = F[wv][lane][set][j];
+                LDS[r * SL_P + sl_slot(k)] = sl_slot(k) >= SL_M ? mk<R>(f.y, f.x) : f;     // mirror half: re / im swapped
                 ++written; ++mine;
             }
             if (mine != 8) return 7;                                              // every thread moves 8 values per set and pass
         }
         if (written != 128 * 128) return 7;
-        // the kernel's lane-level form (t1_pass): the even lane of a pair reads C[c], the odd lane C[-c]; the partner's
-        // value arrives by DPP; p / q pick the components so that one add and one subtract serve both parities
+        // the kernel's lane-level form (t1_pass): the even lane of a pair reads C[c], the odd lane C[-c] with its halves swapped;
+        // the partner's halves arrive by DPP inside one add and one subtract, the same for both parities.  The result is
+        // TWICE the unpacked value (the 1/2 sits in the blend coefficient, blend_one_doubled)
         for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 2 * p; set < 2 * p + 2; ++set) {
             const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63, odd = t & 1;
             for (int j = 0; j < 16; ++j) {
                 const int rho = t + 16 * j, r = rho >> 1;
-                const C d = LDS[r * SL_P + cc], m = LDS[r * SL_P + SL_M + cc];
-                if (std::isnan(d.x) || std::isnan(m.x)) return 8;
-                const C own = odd ? m : d, other = odd ? d : m;                    // other = what the partner lane read
-                const R pp = odd ? own.y : own.x, qq = odd ? own.x : own.y;
-                const R pp_partner = odd ? other.x : other.y, qq_partner = odd ? other.y : other.x;   // the partner has the opposite parity
-                C v = mk<R>((R)0.5 * (pp + qq_partner), (R)0.5 * (qq - pp_partner));
+                const C d = LDS[r * SL_P + cc], ms = LDS[r * SL_P + SL_M + cc];       // ms = the mirror value as stored (swapped)
+                if (std::isnan(d.x) || std::isnan(ms.x)) return 8;
+                const C m = mk<R>(ms.y, ms.x);
+                const C own = odd ? ms : d, other = odd ? d : ms;                  // other = what the partner lane read
+                C v = mk<R>(own.x + other.y, own.y - other.x);
                 const C ref = (rho & 1) ? unpack_b(d, m) : unpack_a(d, m);
-                if (v.x != ref.x || v.y != ref.y) return 12;                       // bit-equal to unpack_a / unpack_b
+                if ((R)0.5 * v.x != ref.x || (R)0.5 * v.y != ref.y) return 12;    // bit-equal to 2 x unpack_a / unpack_b
                 if (c == 0) {
-                    v = odd ? mk<R>(qq_partner, pp) : mk<R>(pp, qq_partner);
+                    v = odd ? mk<R>(other.y, own.x) : mk<R>(own.x, other.y);
                     const C raw = (rho & 1) ? mk<R>(d.y, m.y) : mk<R>(d.x, m.x);
                     if (v.x != raw.x || v.y != raw.y) return 13;
                 }
@@ -136,8 +156,12 @@ int main(int argc, char** argv) {
         } else {
             for (int t = 0; t < 16; ++t) for (int j = 0; j < 16; ++j) {
                 const int lane = 16 * g + t;
-                F[wv][lane][set][j] = blend_one(F[wv][lane][set][j], Yh[yh3_index(0, set, j, wv, lane)],
-                                                (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, ch);
+                const C v2 = F[wv][lane][set][j];                                          // the doubled field
+                const C got = blend_one_doubled(v2, Yh[yh3_index(0, set, j, wv, lane)], (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, (R)0.5 * ch);
+                const C ref = blend_one(mk<R>((R)0.5 * v2.x, (R)0.5 * v2.y), Yh[yh3_index(0, set, j, wv, lane)],
+                                        (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, ch);
+                if (got.x != ref.x || got.y != ref.y) return 17;                          // folding the 1/2 into the coefficient is exact
+                F[wv][lane][set][j] = got;
             }
         }
         group_fft(wv, g, set, true);
@@ -145,19 +169,18 @@ int main(int argc, char** argv) {
     // ---- T2: column form -> row form -------------------------------------------------------------
     for (int p = 0; p < 2; ++p) {
         for (int i = 0; i < SL_BUF; ++i) LDS[i] = mk<R>(NAN, NAN);
-        // the kernel's lane-level form (t2_pass): A = own.x - other.y, B = own.y + other.x; the even lane writes (A, B) to the
-        // direct slot, the odd lane (B, A) to the mirror slot
+        // the kernel's lane-level form (t2_pass): both lanes write (own.x - other.y, own.y + other.x), the even lane to the direct
+        // slot, the odd lane to the mirror slot, whose values are stored with re / im swapped
         for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 2 * p; set < 2 * p + 2; ++set) {
             const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63, odd = t & 1;
             for (int j = 0; j < 16; ++j) {
                 const int r = (t + 16 * j) >> 1;
                 const C own = F[wv][lane][set][j], other = F[wv][lane ^ 1][set][j];
-                const R A = own.x - other.y, Bv = own.y + other.x;
-                C v = odd ? mk<R>(Bv, A) : mk<R>(A, Bv);
+                C v = mk<R>(own.x - other.y, own.y + other.x);
                 const C ue = odd ? other : own, uo = odd ? own : other;
                 const C ref = odd ? repack_q(ue, uo) : repack_p(ue, uo);
-                if (v.x != ref.x || v.y != ref.y) return 14;                       // bit-equal to repack_p / repack_q
-                if (c == 0) v = odd ? mk<R>(other.y, own.y) : mk<R>(own.x, other.x);                  // = (ue.x, uo.x) / (ue.y, uo.y)
+                if (odd ? (v.x != ref.y || v.y != ref.x) : (v.x != ref.x || v.y != ref.y)) return 14;   // bit-equal to repack_p / swapped repack_q
+                if (c == 0) v = odd ? mk<R>(own.y, other.y) : mk<R>(own.x, other.x);                  // = (ue.x, uo.x) / swapped (ue.y, uo.y)
                 LDS[r * SL_P + (odd ? SL_M : 0) + cc] = v;
             }
         }
@@ -166,8 +189,9 @@ int main(int argc, char** argv) {
             for (int j = 0; j < 16; ++j) {
                 const int k = t + 16 * j;
                 if (sl_pass(k) != p) continue;
-                G[wv][lane][set][j] = LDS[r * SL_P + sl_slot(k)];
-                if (std::isnan(G[wv][lane][set][j].x)) return 9;
+                const C got = LDS[r * SL_P + sl_slot(k)];
+                if (std::isnan(got.x)) return 9;
+                G[wv][lane][set][j] = sl_slot(k) >= SL_M ? mk<R>(got.y, got.x) : got;
             }
         }
     }
@@ -180,12 +204,16 @@ int main(int argc, char** argv) {
         for (int j = 0; j < 16; ++j) {
             const int n = t + 16 * j;
             const C o = F[wv][lane][set][j];
-            const int ia = (2 * r) * 256 + n, ib = (2 * r + 1) * 256 + n;
+            const size_t ia = sl_state_index(2 * r, n), ib = sl_state_index(2 * r + 1, n);
             const R xa = std::fabs(o.x) * scale, xb = std::fabs(o.y) * scale;
-            x[ia] = xa; x[ib] = xb;
-            if (cnc) { prox_cnc_pt(xa, z[ia], w[ia], pc); prox_cnc_pt(xb, z[ib], w[ib], pc); }
-            else     { prox_l1_pt(xa, z[ia], w[ia], pc);  prox_l1_pt(xb, z[ib], w[ib], pc); }
+            x[(2 * r) * 256 + n] = xa; x[(2 * r + 1) * 256 + n] = xb;                   // x leaves in natural order
+            if (cnc) { prox_cnc_pt(xa, zs[ia], ws[ia], pc); prox_cnc_pt(xb, zs[ib], ws[ib], pc); }
+            else     { prox_l1_pt(xa, zs[ia], ws[ia], pc);  prox_l1_pt(xb, zs[ib], ws[ib], pc); }
         }
+    }
+    for (int row = 0; row < 256; ++row) for (int n = 0; n < 256; ++n) {              // back to natural order (k_state_order<false>)
+        z[row * 256 + n] = zs[sl_state_index(row, n)];
+        w[row * 256 + n] = ws[sl_state_index(row, n)];
     }
     FILE* o = fopen(argv[2], "wb");
     std::vector<double> d(3 * N);

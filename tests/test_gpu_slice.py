@@ -156,11 +156,14 @@ def test_slice_path_at_every_batch_shape(P, B, monkeypatch):
 
 
 def test_chip_filling_run_matches_the_two_launch_path(P, monkeypatch):
-    """512 slices x 50 CNC iterations (two rounds on every compute unit, the shape bench.py times): x, z, w of the
-    slice-resident kernel against the two-launch path on EVERY slice.  Both paths share the arithmetic cores but not
-    the data flow, so a store that lands wrong anywhere in the batch (buffer-store hazard) shows here:
-    the CNC map amplifies a wrong value, it does not hide it.  fp32 round-off between the two orders of operations
-    grows ~1.08x per iteration: measured max-abs 3e-5 after 50; a misplaced store is O(0.1)."""
+    """512 slices (two rounds on every compute unit, the shape bench.py times): x, z, w of the slice-resident kernel
+    against the two-launch path on EVERY slice.  Both paths share the arithmetic cores but not the data flow, so a
+    store that lands wrong anywhere in the batch (buffer-store hazard) shows here.
+      * 12 iterations: per-pixel max-abs <= 2e-5 (values in [0, 1]).  The CNC map's steepest slope is 1.27, so
+        round-off differences of 1e-7 can reach 1e-7 x 1.27^12 = 2e-6 in a pixel; a misplaced store is O(0.1).
+      * 38 more (50 in all, continuing the same state): per-pixel amplification may now reach 1.27^50 = 1.5e5, so the
+        check is per slice in L2: <= 3e-4 of the slice's norm (float32 vs float64 is 2.6e-5 here; four wrong values
+        of 0.1 in one row are 2e-3 before the map amplifies them)."""
     from pnp_admm_cnc_mri_amd import synthetic as S
     m = S.reference_masks()
     masks = np.stack([m['Q_Random30']]).astype(np.uint8)
@@ -171,10 +174,16 @@ def test_chip_filling_run_matches_the_two_launch_path(P, monkeypatch):
         monkeypatch.setenv('PNP_SLICE', mode)
         with P.Engine(256, 256, Bmax=B) as eng:
             eng.synthesize(img, noise, masks, np.zeros(B, np.int32))
+            assert eng.path_name == ('slice' if mode == '1' else 'fused')
             eng.init_state()
-            eng.admm_cnc(50, 0.45, 0.5, 0.05, 64)
-            res[mode] = (eng.x(), *eng.get_state())
-    for name, a, b in zip('xzw', res['1'], res['0']):
+            eng.admm_cnc(12, 0.45, 0.5, 0.05, 64)
+            early = (eng.x(), *eng.get_state())
+            eng.admm_cnc(38, 0.45, 0.5, 0.05, 64)
+            res[mode] = (early, (eng.x(), *eng.get_state()))
+    for name, a, b in zip('xzw', res['1'][0], res['0'][0]):
         d = np.abs(a.astype(np.float64) - b.astype(np.float64)).reshape(B, -1).max(axis=1)
-        assert d.max() <= 1e-3, (name, int(d.argmax()), float(d.max()))
-        assert np.median(d) <= 1e-4, (name, float(np.median(d)))
+        assert d.max() <= 2e-5, (name, int(d.argmax()), float(d.max()))
+    zn = np.linalg.norm(res['0'][1][1].astype(np.float64).reshape(B, -1), axis=1)
+    for name, a, b in zip('xzw', res['1'][1], res['0'][1]):
+        d = np.linalg.norm((a.astype(np.float64) - b.astype(np.float64)).reshape(B, -1), axis=1) / zn
+        assert d.max() <= 3e-4 and np.median(d) <= 5e-5, (name, int(d.argmax()), float(d.max()), float(np.median(d)))
