@@ -79,7 +79,7 @@ struct pnp_ctx {
     Fused512* fused5 = nullptr;       // 512 x 512
     Slice256* slice = nullptr;        // 256 x 256 slice-resident loops (whole runs; pnp_dc_step stays on `fused`)
     bool slice_ready = false;
-    bool state_sliced = false;       // c->z / c->w are in the slice-resident kernel's order (slice_layout.h, sl_state_pos)
+    bool state_sliced = false;       // c->z / c->w are in the slice-resident kernel's order (slice_layout.h, sl_state_index)
     int slice_min_b = 0;              // batches at least this large run their loops slice-resident
     bool slice_force = false;
     Fused256S<float>* fs32 = nullptr;   // 256 x 256 "split chain" engine in float (PNP_FUSED_COLS=2) ...

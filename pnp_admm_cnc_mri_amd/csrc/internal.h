@@ -139,7 +139,7 @@ Slice256*  slice256_create(int Bmax, hipError_t* err);
 void       slice256_destroy(Slice256*);
 int        slice256_cus(const Slice256*);     // compute units of the device (= slices in flight)
 hipError_t slice256_prepare(Slice256*, hipStream_t s, const float2* y, const uint8_t* mask_bank, const int32_t* mask_id, int B);
-// z, w in SLICE ORDER (slice_layout.h, sl_state_pos); x comes out in natural order
+// z, w in SLICE ORDER (slice_layout.h, sl_state_index); x comes out in natural order
 hipError_t slice256_run(Slice256*, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc, float dc_c,
                         ProxParams p, const FusedSchedule& sch);
 // in-place conversion of both state arrays [B][256][256] between natural order and slice order

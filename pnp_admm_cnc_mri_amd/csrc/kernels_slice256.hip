@@ -197,7 +197,7 @@ __device__ __forceinline__ void group_fft256(c32 (&ac)[16], const c32* twl, c32*
 
 // ------------------------------------------------------------------------------------------
 // rows: one register set = the share of 4 row pairs (8 image rows) this wave owns; lane (g, t) holds elements
-// t + 16 j of row pair 32 set + 4 wave + g.  z / w are stored in HBM in the SAME order (sl_state_pos, slice_layout.h):
+// t + 16 j of row pair 32 set + 4 wave + g.  z / w are stored in HBM in the SAME order (sl_state_index, slice_layout.h):
 // the lane's q-th 16-byte access of a row pair is (row 2r, row 2r + 1) x (j = 2q, 2q + 1) = the register pairs
 // a[2q], a[2q + 1], so the whole z- / w-update runs on the transform's registers.  (Until round 3 the state was in
 // natural order and every set went through LDS twice to meet it; that was a third of the kernel's LDS traffic.)
@@ -208,17 +208,20 @@ struct RowLoads {              // [q][(j & 1) * 2 + sel]
     float z[8][4], w[8][4];
 };
 __device__ __forceinline__ int row_set_offset(int set, int wv) { return (32 * set + 4 * wv) * 2048; }     // bytes; wave-uniform
+constexpr int ROW_QSTRIDE = SLICE_STATE_QMAJOR ? 1024 : 256;       // bytes between a lane's consecutive accesses of a set
 
 // voff = 2048 g + 16 t (bytes inside the wave's 8 KiB of a set); the q-th access adds 256 q as an instruction offset
 template <int PROX, bool HAS_INV, int Q0, int Q1>
 __device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L, int soff, int voff, int qbase = 0) {
 #pragma unroll
     for (int q = qbase + Q0; q < qbase + Q1; ++q) {
+        // instruction offsets reach 4095: the upper half of a q-major chunk goes through the scalar offset
+        const int vo = voff + ROW_QSTRIDE * q - (ROW_QSTRIDE * q >= 4096 ? 4096 : 0), so = soff + (ROW_QSTRIDE * q >= 4096 ? 4096 : 0);
         if (PROX == 3) {                                                   // single-state ADMM_L1: only the w buffer (it carries u)
-            ld4(b.w, voff + 256 * q, soff, L.w[q]);
+            ld4(b.w, vo, so, L.w[q]);
         } else if (PROX != 0 || !HAS_INV) {
-            ld4(b.z, voff + 256 * q, soff, L.z[q]);
-            ld4(b.w, voff + 256 * q, soff, L.w[q]);
+            ld4(b.z, vo, so, L.z[q]);
+            ld4(b.w, vo, so, L.w[q]);
         }
     }
 }
@@ -319,7 +322,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
                                           c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
-    const int voff = 2048 * g + 16 * t;
+    const int voff = SLICE_STATE_QMAJOR ? 16 * lane : 2048 * g + 16 * t;
     // PF accesses of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
     constexpr int PF = (PROX == 3) ? 8 : SLICE_PF;
     RowLoads L;
@@ -340,7 +343,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q + PF < 8) issue_row_loads<PROX, HAS_INV, 0, 1>(b, L, soff, voff, q + PF);
-            pointwise_q<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, a[2 * q], a[2 * q + 1], L.z[q], L.w[q], vs + 256 * q);
+            pointwise_q<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, a[2 * q], a[2 * q + 1], L.z[q], L.w[q], vs + ROW_QSTRIDE * q);
 #ifdef SLICE_PW_SCHED
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -611,40 +614,49 @@ __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* m
 }
 
 // ------------------------------------------------------------------------------------------
-// natural order <-> slice order of the state arrays (sl_state_pos), in place: one block per (row pair, slice), 128
-// threads x 16 bytes per array.  Runs when a context's loops switch kernel families or the caller reads / writes the state.
+// natural order <-> slice order of the state arrays (sl_state_index), in place: one block per (4 row pairs, slice), 128
+// threads x 4 x 16 bytes per array.  Runs when a context's loops switch kernel families or the caller reads / writes the state.
 // ------------------------------------------------------------------------------------------
 template <bool TO_SLICE>
 __global__ __launch_bounds__(128) void k_state_order(float* z, float* w) {
-    __shared__ float tile[2][512];
-    const int i = threadIdx.x, sel = i >> 6, n0 = 4 * (i & 63);
-    const size_t base = ((size_t)blockIdx.y * 128 + blockIdx.x) * 512;
+    __shared__ float tile[2][2048];                       // one chunk = 4 row pairs = 8 image rows of the slice, both arrays
+    const size_t base = ((size_t)blockIdx.y * 32 + blockIdx.x) * 2048;
     float4* pz = reinterpret_cast<float4*>(z + base);
     float4* pw = reinterpret_cast<float4*>(w + base);
-    const float4 vz = pz[i], vw = pw[i];
-    const float az[4] = {vz.x, vz.y, vz.z, vz.w}, aw[4] = {vw.x, vw.y, vw.z, vw.w};
+    float4 vz[4], vw[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int at = TO_SLICE ? sl_state_pos(sel, n0 + k) : 4 * i + k;
-        tile[0][at] = az[k];
-        tile[1][at] = aw[k];
+    for (int u = 0; u < 4; ++u) { vz[u] = pz[threadIdx.x + 128 * u]; vw[u] = pw[threadIdx.x + 128 * u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 128 * u, row = i >> 6, n0 = 4 * (i & 63);        // natural: float4 i = row (0..7) x pixels n0..n0+3
+        const float az[4] = {vz[u].x, vz[u].y, vz[u].z, vz[u].w}, aw[4] = {vw[u].x, vw[u].y, vw[u].z, vw[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int at = TO_SLICE ? (int)sl_state_index(row, n0 + k) : 4 * i + k;
+            tile[0][at] = az[k];
+            tile[1][at] = aw[k];
+        }
     }
     __syncthreads();
-    float oz[4], ow[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int at = TO_SLICE ? 4 * i + k : sl_state_pos(sel, n0 + k);
-        oz[k] = tile[0][at];
-        ow[k] = tile[1][at];
+    for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 128 * u, row = i >> 6, n0 = 4 * (i & 63);
+        float oz[4], ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int at = TO_SLICE ? 4 * i + k : (int)sl_state_index(row, n0 + k);
+            oz[k] = tile[0][at];
+            ow[k] = tile[1][at];
+        }
+        pz[i] = make_float4(oz[0], oz[1], oz[2], oz[3]);
+        pw[i] = make_float4(ow[0], ow[1], ow[2], ow[3]);
     }
-    pz[i] = make_float4(oz[0], oz[1], oz[2], oz[3]);
-    pw[i] = make_float4(ow[0], ow[1], ow[2], ow[3]);
 }
 
 hipError_t slice256_state_order(hipStream_t s, float* z, float* w, int B, bool to_slice) {
     if (B <= 0) return hipSuccess;
-    if (to_slice) hipLaunchKernelGGL(k_state_order<true>, dim3(128, B), dim3(128), 0, s, z, w);
-    else          hipLaunchKernelGGL(k_state_order<false>, dim3(128, B), dim3(128), 0, s, z, w);
+    if (to_slice) hipLaunchKernelGGL(k_state_order<true>, dim3(32, B), dim3(128), 0, s, z, w);
+    else          hipLaunchKernelGGL(k_state_order<false>, dim3(32, B), dim3(128), 0, s, z, w);
     return hipGetLastError();
 }
 
