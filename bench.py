@@ -98,7 +98,7 @@ def cpu_baseline_all_cores(budget_s=8.0, iters=100):
                       % (cores, budget_s, iters, sum(n for n, _ in res), wall)}
 
 
-def launch_ranks(n, timeout_s):
+def launch_ranks(n, timeout_s, script=None):
     """`python bench.py --gpus N` outside torchrun: start the N rank processes as CHILDREN of this
     process (which has not imported torch and never initialises HIP), one per GPU, with the
     torch.distributed env of a one-node job on 127.0.0.1; relay rank 0's JSON line and return the
@@ -122,7 +122,7 @@ def launch_ranks(n, timeout_s):
         # value wins.
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         outs.append(tempfile.TemporaryFile())
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=outs[r]))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + sys.argv[1:], env=env, stdout=outs[r]))
     rc = 0
     live = list(procs)
     while live:

@@ -1,65 +1,116 @@
 #!/usr/bin/env python3
-"""Auxiliary benchmark (NOT the driver's headline bench.py): PnP configs of BASELINE.json on one
-GPU -- config 3 (PNP_ADMM_CNC_D + FFDNet, 512 slices, Q_Radial30) and the per-GPU shard of config 4
-(DRUNet, 512 slices, Q_Cartesian30) -- reporting iterations/s and the split between the HIP
-x-update/glue kernels and the PyTorch-ROCm denoiser.  Seeded synthetic weights (no network).
+"""Auxiliary benchmark (NOT the driver's headline bench.py): the plug-and-play configurations of BASELINE.json.
 
-    python bench_pnp.py --model ffdnet_gray --batch 512 --steps 10
+    config 3   python bench_pnp.py --model ffdnet_gray --batch 512                      (FFDNet, Q_Radial30, 1 GPU)
+    config 4   python bench_pnp.py --model drunet_gray --batch 512 --gpus 8             (DRUNet, Q_Cartesian30, 8 x 512 slices)
+    config 5   python bench_pnp.py --model drunet_gray --size 512 --batch 256 --gpus 8  (512 x 512, mask bank of 3, 8 x 256 slices)
+
+One step = one PNP_ADMM_CNC_D iteration (S6:266-308) over the slices a GPU holds: x-update in k-space (HIP, pnp_dc_step),
+s = D(z), the CNC combination (HIP), z = D(t), dual update + clamps (HIP).  Slices shard over the GPUs exactly as in
+bench.py (contiguous blocks, no data-path collective, one RCCL gather of x at the end, timed apart); `--gpus N` starts its
+own rank processes through bench.launch_ranks.  Seeded synthetic weights and inputs (no network).
+
+SURVEY.md 8(d) asks, for the PnP configs, for the FFT + prox part's own figure and, separately, the denoiser's time share and
+FLOP/s: `fft_prox` carries time, algorithmic bytes (57 N per slice-iteration) and the HBM fraction; `denoiser` carries time
+share, FLOP per call (2 x the MACs of every convolution actually executed, counted by hooks) and FLOP/s against the fp32
+matrix-core peak of MI355X (157.3 TFLOP/s: MIOpen's fp32 convolutions are what the north star keeps there).
 """
 import argparse
 import json
+import os
+import sys
 import time
 
 import numpy as np
-import torch
 
-import pnp_admm_cnc_mri_amd as P
-from pnp_admm_cnc_mri_amd import denoisers as D, solvers_pnp as SP, synthetic as S, utils_pnp
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MATRIX_PEAK_GFLOPS = 157300.0            # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+HBM_PEAK_GBS = 8000.0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--model', default='ffdnet_gray')
-    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=512, help='slices per GPU')
+    ap.add_argument('--size', type=int, default=256, choices=[256, 512], help='512 = the shape of config 5 (seeded mask bank of 3)')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
-    ap.add_argument('--channels-last', action='store_true')
-    ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'])
-    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+    ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'], help='autocast throughput mode, off parity')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True for the whole run')
+    ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)))
+    ap.add_argument('--rehearse-gloo', action='store_true', help='N > 1 on a box with ONE GPU: gloo backend, all ranks on cuda:0')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import bench                                   # stdlib + numpy only at import: the parent never touches the GPU
+        sys.exit(bench.launch_ranks(args.gpus, args.launch_timeout, script=__file__))
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = 0 if args.rehearse_gloo else int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+
+    import torch
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import denoisers as D, solvers_pnp as SP, synthetic as S, utils_pnp, sharding
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.rehearse_gloo:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
     fam = D.family(args.model)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    mname = args.mask or {'ffdnet': 'Q_Radial30', 'drunet': 'Q_Cartesian30'}.get(fam, 'Q_Random30')
-    mask = S.reference_masks()[mname].astype(np.uint8)
+    H = W = args.size
     B = args.batch
-    img, noise = S.batch(0, B)
+    if H == 256:
+        mname = args.mask or {'ffdnet': 'Q_Radial30', 'drunet': 'Q_Cartesian30'}.get(fam, 'Q_Random30')
+        masks = S.reference_masks()[mname].astype(np.uint8)[None]
+        mask_id = np.zeros(B, np.int32)
+    else:
+        mname = 'seeded bank (random, radial, cartesian)'
+        masks = np.stack([S.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+        mask_id = (np.arange(B) % 3).astype(np.int32)
+    img, noise = S.batch(rank * B, B, H, W)             # this rank's shard of the job
     opts = SP.PRESETS['PNP_ADMM_CNC_D'].get(fam, SP.PRESETS['PNP_ADMM_CNC_DnCNN'])
-    dev = torch.device('cuda', 0)
+    dev = torch.device('cuda', local_rank)
     net, nlm, sched = D.build(args.model)
     net.load_state_dict(D.seeded_state_dict(net, 1))
     iters = args.warmup + args.steps
     sig = None
     if sched:
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
-    if args.channels_last:
-        net = net.to(memory_format=torch.channels_last)
     den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype).to(dev)
-    eng = P.Engine(256, 256, Bmax=B)
-    eng.synthesize(img, noise, mask)
+    flop_per_call = D.forward_flops(den, H, W, dev)     # one slice, one D(.)
+
+    eng = P.Engine(H, W, Bmax=B, device=local_rank)
+    eng.synthesize(img, noise, masks, mask_id)
     eng.init_state()
     eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    z0, w0 = eng.get_state()
-    z = torch.from_numpy(z0).to(dev).reshape(B, 1, 256, 256)
-    w = torch.from_numpy(w0).to(dev).reshape(B, 1, 256, 256)
+    z = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    w = torch.empty_like(z)
+    eng.get_state(z, w)
     x, s, t, zn = (torch.empty_like(z) for _ in range(4))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_dc = t_cnn = 0.0
+    t0 = time.perf_counter()
     with torch.no_grad():
         for i in range(iters):
             if i == args.warmup:
                 torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                    torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 t_dc = t_cnn = 0.0
             ev[0].record()
@@ -75,12 +126,54 @@ def main():
             torch.cuda.synchronize()
             t_dc += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
             t_cnn += ev[1].elapsed_time(ev[2])
-        wall = time.perf_counter() - t0
-    print(json.dumps({'model': args.model, 'mask': mname, 'batch': B, 'steps': args.steps,
-                      'iterations_per_s': args.steps / wall, 'slice_iterations_per_s': args.steps * B / wall,
-                      'ms_per_iteration': wall / args.steps * 1e3,
-                      'ms_dc_and_glue': t_dc / args.steps, 'ms_denoiser_x2': t_cnn / args.steps,
-                      'x_finite': bool(torch.isfinite(x).all()), 'path': eng.path_name}))
+        wall = time.perf_counter() - t0              # this rank's clock stops at its own sync, before any collective
+
+    gather_ms = None
+    if dist is not None:
+        dist.barrier()
+        xg = x.reshape(B, H, W)
+        xg = xg.cpu() if args.rehearse_gloo else xg
+        sharding.gather_slices(xg, world * B, dst=0)                   # untimed: connection set-up
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        x_all = sharding.gather_slices(xg, world * B, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert (x_all is not None) == (rank == 0)
+        tt = torch.tensor([wall, t_dc, t_cnn, gather_ms], dtype=torch.float64, device='cpu' if args.rehearse_gloo else 'cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, t_dc, t_cnn, gather_ms = (float(v) for v in tt.cpu())
+    if rank == 0:
+        K = args.steps
+        dc_ms, cnn_ms = t_dc / K, t_cnn / K
+        den_flop = 2.0 * flop_per_call * B                              # two D(.) per iteration, every slice
+        den_gflops = den_flop / (cnn_ms * 1e-3) / 1e9
+        alg_bytes = 57.0 * H * W * B
+        print(json.dumps({
+            'metric': 'PNP_ADMM_CNC_D iterations/sec on %dx%d slices (%s)' % (H, W, args.model),
+            'value': world * K / wall * (B / 512.0), 'unit': 'it/s (512-slice batches)', 'n_gpus': world, 'steps': K,
+            'warmup': args.warmup, 'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'dtype': 'f32' if args.cnn_dtype is None else args.cnn_dtype, 'data': 'synthetic (seeded weights)',
+            'config': {'workload': 'PNP_ADMM_CNC_D, %s, %d synthetic %dx%d slices per GPU, %s, S6:569-577 presets'
+                                   % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
+                       'cnn_batch': args.cnn_batch},
+            'slice_iterations_per_s': world * K * B / wall, 'gather_ms': gather_ms,
+            'fft_prox': {'ms_per_step': dc_ms, 'share': dc_ms / (dc_ms + cnn_ms), 'algorithmic_bytes': alg_bytes,
+                         'roofline': {'bound': 'hbm', 'achieved': alg_bytes / (dc_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'frac': alg_bytes / (dc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         'note': 'pnp_dc_step + pnp_cnc_combine is inside the denoiser span; pnp_dual_clamp is here; '
+                                 '57 N bytes per slice-iteration is the contract figure of the whole FFT + prox iteration'},
+            'denoiser': {'ms_per_step': cnn_ms, 'share': cnn_ms / (dc_ms + cnn_ms), 'calls_per_step': 2,
+                         'flop_per_call_per_slice': flop_per_call, 'flop_per_step': den_flop,
+                         'roofline': {'bound': 'mfma_f32', 'achieved': den_gflops, 'peak': F32_MATRIX_PEAK_GFLOPS, 'unit': 'GFLOP/s',
+                                      'frac': den_gflops / F32_MATRIX_PEAK_GFLOPS},
+                         'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)'},
+            'x_finite': bool(torch.isfinite(x).all())}), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -58,12 +58,23 @@ template <typename C> __device__ __forceinline__ C cmulc(C a, C b) {   // a * co
 template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return mkc(a.x + b.x, a.y + b.y); }
 template <typename C> __device__ __forceinline__ C csub(C a, C b) { return mkc(a.x - b.x, a.y - b.y); }
 
-// Length-N transform of the contiguous LDS array `a` by T cooperating threads (t in [0,T)),
-// scratch `b`; all threads of the workgroup must call it (block barriers inside).
+// The T threads of one transform are lanes of ONE wavefront (T <= 64, groups aligned to T): a wave's LDS instructions
+// execute in order, so the stages need no workgroup barrier -- only the compiler has to keep the order.  (Until round 3
+// every stage ended in __syncthreads(): 9-10 workgroup barriers per transform held every column of a tile to the pace of
+// the slowest wave; the column kernel ran at 0.18 of the HBM roofline.)
+__device__ __forceinline__ void stage_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Length-N transform of the contiguous LDS array `a` by T cooperating lanes of one wave (t in [0,T)), scratch `b`.
+// No workgroup barrier inside: the caller orders its own cross-wave accesses around the call.
 // Returns the buffer holding the result (natural order).
 template <int N, int T, bool INV, typename C>
 __device__ __forceinline__ C* fft_lds(C* a, C* b, const C* tw, int t) {
     static_assert(N == 256 || N == 512, "N");
+    static_assert(T <= 64 && 64 % T == 0, "the lanes of a transform must share a wavefront");
     int Ns = 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -85,7 +96,7 @@ __device__ __forceinline__ C* fft_lds(C* a, C* b, const C* tw, int t) {
             b[j0 + 2 * Ns] = csub(t0, t2);
             b[j0 + 3 * Ns] = csub(t1, t3);
         }
-        __syncthreads();
+        stage_sync();
         C* tmp = a; a = b; b = tmp;
         Ns *= 4;
     }
@@ -98,7 +109,7 @@ __device__ __forceinline__ C* fft_lds(C* a, C* b, const C* tw, int t) {
             b[j0] = cadd(v0, v1);
             b[j0 + 256] = csub(v0, v1);
         }
-        __syncthreads();
+        stage_sync();
         C* tmp = a; a = b; b = tmp;
     }
     return a;
@@ -243,6 +254,7 @@ __global__ __launch_bounds__(256) void k_cols(ColArgsT<R> p, int W) {
         if (r != sA + c_f * P) { cur = sB; oth = sA; }
     }
     if (MID != MID_NONE) {
+        __syncthreads();                                  // the pointwise pass walks the tile row-major: other waves' columns
         const int mid = p.mask_id ? p.mask_id[b] : 0;
         const uint8_t* mask = p.mask_bank + (size_t)mid * N * W;
         const C* yb = p.y + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
@@ -269,6 +281,7 @@ __global__ __launch_bounds__(256) void k_cols(ColArgsT<R> p, int W) {
         C* r = fft_lds<N, T, true>(cur + c_f * P, oth + c_f * P, sTw, t_f);
         if (r != cur + c_f * P) { C* tmp = cur; cur = oth; oth = tmp; }
     }
+    __syncthreads();
     for (int idx = tid; idx < N * COLS; idx += 256) {
         const int r = idx / COLS, c = idx % COLS;
         p.out[sbase + (size_t)r * W + k0 + c] = cur[c * P + r];

@@ -208,15 +208,14 @@ struct RowLoads {              // [q][(j & 1) * 2 + sel]
     float z[8][4], w[8][4];
 };
 __device__ __forceinline__ int row_set_offset(int set, int wv) { return (32 * set + 4 * wv) * 2048; }     // bytes; wave-uniform
-constexpr int ROW_QSTRIDE = SLICE_STATE_QMAJOR ? 1024 : 256;       // bytes between a lane's consecutive accesses of a set
+constexpr int ROW_QSTRIDE = 256;                                  // bytes between a lane's consecutive accesses of a row pair
 
 // voff = 2048 g + 16 t (bytes inside the wave's 8 KiB of a set); the q-th access adds 256 q as an instruction offset
 template <int PROX, bool HAS_INV, int Q0, int Q1>
 __device__ __forceinline__ void issue_row_loads(const SliceBufs& b, RowLoads& L, int soff, int voff, int qbase = 0) {
 #pragma unroll
     for (int q = qbase + Q0; q < qbase + Q1; ++q) {
-        // instruction offsets reach 4095: the upper half of a q-major chunk goes through the scalar offset
-        const int vo = voff + ROW_QSTRIDE * q - (ROW_QSTRIDE * q >= 4096 ? 4096 : 0), so = soff + (ROW_QSTRIDE * q >= 4096 ? 4096 : 0);
+        const int vo = voff + ROW_QSTRIDE * q, so = soff;
         if (PROX == 3) {                                                   // single-state ADMM_L1: only the w buffer (it carries u)
             ld4(b.w, vo, so, L.w[q]);
         } else if (PROX != 0 || !HAS_INV) {
@@ -322,7 +321,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
                                           c32* wreg, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
-    const int voff = SLICE_STATE_QMAJOR ? 16 * lane : 2048 * g + 16 * t;
+    const int voff = 2048 * g + 16 * t;
     // PF accesses of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
     constexpr int PF = (PROX == 3) ? 8 : SLICE_PF;
     RowLoads L;

@@ -66,21 +66,11 @@ PNP_HD size_t mh3_index(int slice, int set, int wv, int lane) { return (size_t)s
 // i.e. lane t's q-th 16-byte access (q = 0..7) holds (row 2r, row 2r+1) x (j = 2q, 2q + 1) = its registers a[2q], a[2q + 1].
 // pnp_get_state / pnp_set_state / the other kernel families see the natural [256][256] order: api.hip converts in place
 // (k_state_order) when a run switches families.  x is always natural.
-#ifndef SLICE_STATE_QMAJOR
-#define SLICE_STATE_QMAJOR 0
-#endif
-#if SLICE_STATE_QMAJOR
-// variant: the four row pairs a wave handles in one register set (a chunk of 2048 floats) are interleaved so that EVERY
-// 16-byte-per-lane wave access is 1 KiB contiguous:  chunk 2048 (r >> 2) + 256 q + 64 (r & 3) + 4 t + 2 (j & 1) + sel
-PNP_HD size_t sl_state_index(int row, int n) {
-    const int r = row >> 1;
-    return (size_t)(r >> 2) * 2048 + 256 * (n >> 5) + 64 * (r & 3) + 4 * (n & 15) + 2 * ((n >> 4) & 1) + (row & 1);
-}
-#else
 PNP_HD size_t sl_state_index(int row, int n) {                 // within the slice's 65536 floats
     return (size_t)(row >> 1) * 512 + 64 * (n >> 5) + 4 * (n & 15) + 2 * ((n >> 4) & 1) + (row & 1);
 }
-#endif
+// (A variant that interleaves the four row pairs of a wave's register set so that every wave access is 1 KiB contiguous
+// instead of 4 x 256 bytes measured the same, 10.3 k it/s: the kernel is at the memory system's limit for its bytes.)
 
 // the packed column c = 0 after its transform: G[k1] = A[k1] + i B[k1] with A, B the transforms of the
 // REAL columns k2 = 0 and k2 = 128:  A = unpack_a(G[k1], G[-k1]),  B = unpack_b(G[k1], G[-k1]),

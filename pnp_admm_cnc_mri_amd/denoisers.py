@@ -232,6 +232,28 @@ def test_mode(model, L, mode=0, refield=32, min_size=256, sf=1, modulo=1):
     raise NotImplementedError('test_mode %d is not reached by the PnP solvers' % mode)
 
 
+def forward_flops(den, H, W, device):
+    """Floating-point operations of ONE denoiser call on one H x W slice: 2 x the multiply-accumulates of every
+    Conv2d / ConvTranspose2d the call really executes (counted by forward hooks on a one-slice probe, so the quadrant split of
+    DRUNet above 256 x 256 and the 1/4-resolution FFDNet body are what they are, not what a formula assumes)."""
+    macs = [0]
+
+    def hook(m, inp, out):
+        kh, kw = m.kernel_size
+        if isinstance(m, torch.nn.ConvTranspose2d):
+            macs[0] += inp[0].numel() * (m.out_channels // m.groups) * kh * kw
+        else:
+            macs[0] += out.numel() * (m.in_channels // m.groups) * kh * kw
+
+    hs = [m.register_forward_hook(hook) for m in den.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+    try:
+        den(torch.rand((1, 1, H, W), dtype=torch.float32, device=device), 0)
+    finally:
+        for h in hs:
+            h.remove()
+    return 2 * macs[0]
+
+
 class Denoiser:
     """`denoising_step2` (S6:18-67) == `denoising_step1` (S3:19-68) bound to one model: maps a
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""

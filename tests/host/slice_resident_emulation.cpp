@@ -83,11 +83,7 @@ int main(int argc, char** argv) {
         }
     }
     // the lane's q-th 16-byte access of row pair r: floats 512 r + 64 q + 4 t .. + 3 = (row 2r, row 2r+1) x (j = 2q, 2q + 1)
-#if SLICE_STATE_QMAJOR
-    auto lane_access = [](int r, int t, int q, int k) { return (size_t)2048 * (r >> 2) + 256 * q + 64 * (r & 3) + 4 * t + k; };
-#else
     auto lane_access = [](int r, int t, int q, int k) { return (size_t)512 * r + 64 * q + 4 * t + k; };
-#endif
     for (int r = 0; r < 128; ++r) for (int t = 0; t < 16; ++t) for (int q = 0; q < 8; ++q) for (int k = 0; k < 4; ++k)
         if (lane_access(r, t, q, k) != sl_state_index(2 * r + (k & 1), t + 16 * (2 * q + (k >> 1)))) return 16;
     // ---- rows (first): F <- row transforms of the row pairs ------------------------------------

@@ -151,3 +151,16 @@ def test_denoiser_call_restores_the_cudnn_benchmark_flag():
             Boom('ffdnet_gray', net.eval(), nlm, miopen_find=True)(x, 0)
         assert torch.backends.cudnn.benchmark is before
     torch.backends.cudnn.benchmark = False
+
+
+@pytest.mark.parametrize('name,gflop', [('ffdnet_gray', 15.9), ('dncnn_15', 72.6), ('drunet_gray', 277.0)])
+def test_forward_flops_match_the_survey(name, gflop):
+    """bench_pnp.py prices the denoiser at 2 x the MACs its convolutions really execute (hooks on a one-slice call);
+    the figures of SURVEY.md section 8 (a12): FFDNet 15.9, DnCNN-17 72.6, DRUNet 277 GFLOP per 256 x 256 forward."""
+    import torch
+    from pnp_admm_cnc_mri_amd import denoisers as D
+    net, nlm, sched = D.build(name)
+    sig = torch.full((4,), 0.1) if sched else None
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=np.zeros((256, 256), np.complex64), miopen_find=False)
+    got = D.forward_flops(den, 256, 256, 'cpu') / 1e9
+    assert abs(got - gflop) <= 0.02 * gflop, got

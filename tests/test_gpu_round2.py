@@ -476,3 +476,25 @@ def test_bench_line_carries_parity_and_the_f64_record():
     assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5
     assert j['f64']['dtype'] == 'f64' and j['f64']['value'] > 0 and max(j['f64']['rel_l2_vs_oracle']) <= 1e-9
     assert j['cpu_baseline']['cores'] == 1 and j['roofline']['traffic_measured_in_this_run'] is False
+
+
+def test_bench_pnp_line_and_its_two_rank_launch():
+    """bench_pnp.py (configs 3-5): the line carries the FFT + prox part's bytes / time / HBM fraction and, separately, the
+    denoiser's share, FLOP per call and FLOP/s against the fp32 matrix peak; `--gpus 2` launches its own
+    ranks like bench.py (both on this box's one GPU, gloo rendezvous) and times the gather apart."""
+    env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    base = [sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', 'ffdnet_gray', '--batch', '16', '--steps', '2', '--warmup', '1']
+    r = subprocess.run(base, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert j['n_gpus'] == 1 and j['gather_ms'] is None and j['x_finite']
+    assert abs(j['denoiser']['flop_per_call_per_slice'] / 1e9 - 15.9) <= 0.4
+    assert j['denoiser']['roofline']['bound'] == 'mfma_f32' and 0 < j['denoiser']['roofline']['frac'] < 1
+    assert j['fft_prox']['roofline']['bound'] == 'hbm' and j['fft_prox']['algorithmic_bytes'] == 57.0 * 65536 * 16
+    assert abs(j['denoiser']['share'] + j['fft_prox']['share'] - 1) < 1e-9
+    r2 = subprocess.run(base + ['--gpus', '2', '--rehearse-gloo'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r2.returncode == 0, r2.stderr.decode()[-3000:]
+    lines = [l for l in r2.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j2 = json.loads(lines[0])
+    assert j2['n_gpus'] == 2 and j2['gather_ms'] is not None and j2['scaling'] == 'weak' and j2['x_finite']
