@@ -12,6 +12,7 @@
 //            same row routine runs on it (16 lanes per column); global accesses are 128-B row
 //            segments; the LDS pitch N+1 keeps the transposing writes conflict-free.
 #include "internal.h"
+#include "fft16.h"
 #include <math.h>
 
 namespace pnp {
@@ -318,10 +319,133 @@ static hipError_t launch_cols_n(hipStream_t s, int W, bool pre, ColMid mid, bool
     return hipErrorInvalidValue;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// columns of 256-row float arrays: the register transform of fft16.h (16 lanes x 16 points, ONE exchange through LDS)
+// instead of four LDS stages.  Same tile (16 columns x 256 rows, 128-byte row segments in global memory), same
+// pointwise pass; the Stockham kernel above stays for 512 rows and for double.
+// (k_cols<256, true, 1, true, float> ran 526-536 us at 512 slices = 1.48 TB/s, bound by the latency of eight dependent
+// LDS stages at two workgroups per compute unit; this one holds 40 KB of LDS: four workgroups per compute unit.)
+// Tile pitch 273 complex: = 1 mod 16, so the transposing tile writes of 16 lanes (one row, 16 columns) hit 16 distinct
+// bank pairs, and = 17 mod 32, so the b64 column reads of a 32-lane group (two columns x 16 lanes) overlap in one pair only.
+// ------------------------------------------------------------------------------------------
+constexpr int C16_P = 273;
+
+template <bool INV>
+__device__ __forceinline__ void col16_fft(c32 (&a)[16], const c32* twl, c32* col, int t) {
+    {
+        c32 tw[16];                                 // the lane's row of the table, fetched per transform (not held across the kernel)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tw[k] = twl[17 * t + k];
+        fft256_head<INV>(a, tw);
+    }
+    stage_sync();                                   // every lane of the column holds its inputs: the column's slot is free
+#pragma unroll
+    for (int k = 0; k < 16; ++k) col[k * 17 + t] = a[k];
+    stage_sync();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) a[n] = col[t * 17 + n];
+    stage_sync();
+    fft256_tail<INV>(a);
+}
+
+template <bool PRE, int MID, bool POST>
+__global__ __launch_bounds__(256) void k_cols16(ColArgsT<float> p, int W) {
+    __shared__ __attribute__((aligned(16))) c32 tile[16 * C16_P];
+    __shared__ c32 twl[16 * 17];
+    const int tid = threadIdx.x;
+    {
+        const float2 wv = g_tw256[((tid >> 4) * (tid & 15)) & 255];
+        twl[17 * (tid >> 4) + (tid & 15)] = mk<float>(wv.x, wv.y);          // [t][k] = W256^(t k)
+    }
+    const int tiles = W / 16;
+    const int b = blockIdx.x / tiles;
+    const int k0 = (blockIdx.x % tiles) * 16;
+    const size_t sbase = (size_t)b * 256 * W;
+    const c32* in = reinterpret_cast<const c32*>(p.in);
+    c32* out = reinterpret_cast<c32*>(p.out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
+        tile[c * C16_P + r] = in[sbase + (size_t)r * W + k0 + c];
+    }
+    __syncthreads();
+    const int c = tid >> 4, t = tid & 15;
+    c32* col = tile + c * C16_P;
+    c32 a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = col[t + 16 * j];
+    if (PRE) col16_fft<false>(a, twl, col, t);
+    if (MID != MID_NONE) {
+        stage_sync();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) col[t + 16 * j] = a[j];
+        __syncthreads();                                  // the pointwise pass walks the tile row-major (coalesced y / mask reads)
+        const int mid = p.mask_id ? p.mask_id[b] : 0;
+        const uint8_t* mask = p.mask_bank + (size_t)mid * 256 * W;
+        const c32* yb = reinterpret_cast<const c32*>(p.y) + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 4, cc = idx & 15;
+            const size_t g = (size_t)r * W + k0 + cc;
+            c32 X = tile[cc * C16_P + r];
+            const bool m = mask[g] != 0;
+            if (MID == MID_BLEND) {
+                if (m) { const c32 yv = yb[g]; X.x = fmaf(yv.x - X.x, p.c, X.x); X.y = fmaf(yv.y - X.y, p.c, X.y); }
+            } else if (MID == MID_MASK) {
+                if (!m) X = mk<float>(0.f, 0.f);
+            } else if (MID == MID_RESID) {
+                if (m) { const c32 yv = yb[g]; X.x -= yv.x; X.y -= yv.y; } else X = mk<float>(0.f, 0.f);
+            } else if (MID == MID_MASK_ADD) {
+                const c32 nv = yb[g];
+                X = m ? X + nv : nv;
+            }
+            tile[cc * C16_P + r] = X;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = col[t + 16 * j];
+    }
+    if (POST) col16_fft<true>(a, twl, col, t);
+    stage_sync();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) col[t + 16 * j] = a[j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, r = idx >> 4, cc = idx & 15;
+        out[sbase + (size_t)r * W + k0 + cc] = tile[cc * C16_P + r];
+    }
+}
+
+template <bool PRE, int MID, bool POST>
+static hipError_t launch_cols16(hipStream_t s, int W, const ColArgsT<float>& a) {
+    hipLaunchKernelGGL((k_cols16<PRE, MID, POST>), dim3(a.B * (W / 16)), dim3(256), 0, s, a, W);
+    return hipGetLastError();
+}
+static hipError_t launch_cols16_any(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
+    if (pre && !post && mid == MID_NONE)      return launch_cols16<true, MID_NONE, false>(s, W, a);
+    if (!pre && post && mid == MID_NONE)      return launch_cols16<false, MID_NONE, true>(s, W, a);
+    if (pre && post && mid == MID_BLEND)      return launch_cols16<true, MID_BLEND, true>(s, W, a);
+    if (pre && !post && mid == MID_MASK)      return launch_cols16<true, MID_MASK, false>(s, W, a);
+    if (!pre && post && mid == MID_MASK)      return launch_cols16<false, MID_MASK, true>(s, W, a);
+    if (pre && post && mid == MID_RESID)      return launch_cols16<true, MID_RESID, true>(s, W, a);
+    if (pre && !post && mid == MID_MASK_ADD)  return launch_cols16<true, MID_MASK_ADD, false>(s, W, a);
+    return hipErrorInvalidValue;
+}
+template <typename R> static hipError_t cols16_or_stockham(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a);
+template <> hipError_t cols16_or_stockham<float>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
+    static const bool stockham = getenv("PNP_GENERIC_STOCKHAM") != nullptr;      // developer knob: the four-stage LDS kernel (A/B runs)
+    return stockham ? launch_cols_n<256>(s, W, pre, mid, post, a) : launch_cols16_any(s, W, pre, mid, post, a);
+}
+template <> hipError_t cols16_or_stockham<double>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<double>& a) {
+    return launch_cols_n<256>(s, W, pre, mid, post, a);
+}
+
 template <typename R>
 hipError_t launch_cols(hipStream_t s, int H, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a) {
     if (W % 16) return hipErrorInvalidValue;
-    if (H == 256) return launch_cols_n<256>(s, W, pre, mid, post, a);
+    if (H == 256) return cols16_or_stockham<R>(s, W, pre, mid, post, a);
     if (H == 512) return launch_cols_n<512>(s, W, pre, mid, post, a);
     return hipErrorInvalidValue;
 }
