@@ -35,6 +35,12 @@
 #include <stdlib.h>
 #include <vector>
 
+#ifndef SLICE_YH_AUX
+#define SLICE_YH_AUX 0      // cache policy bits of the Hermitian-table loads (experiment knob: 2 = nt)
+#endif
+#ifndef SLICE_ST_AUX
+#define SLICE_ST_AUX 0      // cache policy bits of the state stores (experiment knob)
+#endif
 #ifndef SLICE_PF
 #define SLICE_PF 3          // of a set's 8 z / w accesses per lane: fetched ahead of the transforms (experiment knob)
 #endif
@@ -52,6 +58,7 @@ struct SliceArgs {
     const c32* Ys;            // [B][256]   k2 = 128
     const uint32_t* Ms;       // [B][16]
     int first, B, iters;      // slices [first, first + B) of the arrays; iterations of this launch
+    int slice_xor;            // experiment knob (PNP_SLICE_XOR): workgroup b takes slice b ^ slice_xor (both below B)
     float scale, c;
     ProxCoef prox;
     long long* prof;          // phase clock dump of a -DSLICE_PROF build (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
@@ -117,7 +124,7 @@ __device__ __forceinline__ void st4(bufrsrc r, int voff, int soff, const float (
     if (q.x == 0x7fc12345u) __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, 0);
     return;
 #endif
-    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, SLICE_ST_AUX);
 }
 __device__ __forceinline__ c32 ldc(bufrsrc r, int voff, int soff) {
     const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
@@ -486,7 +493,7 @@ __device__ __forceinline__ void issue_col_loads(const SliceBufs& b, ColLoads& Y,
     Y.code = __builtin_amdgcn_raw_buffer_load_b32(b.mh, 4 * lane, (set * 8 + wv) * 64 * 4, 0);
 #pragma unroll
     for (int jp = 0; jp < 8; ++jp) {                               // (j = 2 jp, 2 jp + 1) per 16-byte access; offsets 0 .. 3072 are instruction immediates
-        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(b.yh, 16 * lane + 1024 * (jp & 3), ybase + 4096 * (jp >> 2), 0);
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(b.yh, 16 * lane + 1024 * (jp & 3), ybase + 4096 * (jp >> 2), SLICE_YH_AUX);
         Y.yh[2 * jp] = mk<float>(__uint_as_float(q.x), __uint_as_float(q.y));
         Y.yh[2 * jp + 1] = mk<float>(__uint_as_float(q.z), __uint_as_float(q.w));
     }
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     c32* wreg = lds + wv * WREG;
     __syncthreads();
     for (int sb = blockIdx.x; sb < p.B; sb += gridDim.x) {
-        const int slice = p.first + sb;
+        const int slice = p.first + (((sb ^ p.slice_xor) < p.B) ? (sb ^ p.slice_xor) : sb);
         const size_t so = (size_t)slice * 65536;
         SliceBufs b;
         b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + so, 65536 * 4);
@@ -751,7 +758,10 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     a.first = 0; a.B = B; a.iters = iters; a.scale = 1.0f / 65536.0f; a.c = dc_c;
     a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
     a.prof = nullptr;
+    a.slice_xor = 0;
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    a.slice_xor = env_int("PNP_SLICE_XOR", 0);
+    if (a.slice_xor < 0 || (B & (B - 1)) != 0 || a.slice_xor >= B) a.slice_xor = 0;      // a permutation only for power-of-two batches
     const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
     int queues = env_int("PNP_SLICE_QUEUES", 1), seg_len = env_int("PNP_SLICE_SEGMENT", 0);   // measured: 1 launch is best
     if (queues < 1) queues = 1;

@@ -39,3 +39,18 @@ for rnd, sel in (('first 256 blocks', slice(0, 256)), ('blocks 256..', slice(256
     dd = d_all[sel]
     if len(dd):
         print(rnd, 'duration by blockIdx %% 8:', np.round([np.median(dd[r::8]) for r in range(8)], 0))
+
+# per-phase medians by blockIdx % 8 for the first round (one workgroup per compute unit, all started together):
+# a phase that touches no memory (T1, T2) separates clock differences between XCDs from memory-path differences
+ph_all = raw_all[:, 2:].reshape(B, iters, 6)
+prev_all = np.concatenate([raw_all[:, 1:2], ph_all[:, :-1, 5]], axis=1)
+nfirst = min(256, B)
+print('first-round medians by blockIdx %% 8 (us): wait(rows) T1 columns wait(cols) T2 rows | iteration')
+for r in range(8):
+    sel = np.arange(r, nfirst, 8)
+    row = []
+    for k in range(6):
+        d = ph_all[sel, :, k] - (prev_all[sel] if k == 0 else ph_all[sel, :, k - 1])
+        row.append(np.median(d))
+    it = np.median(ph_all[sel, :, 5] - prev_all[sel])
+    print('  %d: ' % r + ' '.join('%6.2f' % v for v in row) + ' | %6.2f' % it)
