@@ -66,7 +66,6 @@ struct pnp_ctx {
     float2* y = nullptr;              // [Bmax][H][W]
     float2* work = nullptr;           // [Bmax][H][W] transform intermediate
     float *z = nullptr, *w = nullptr, *x = nullptr;
-    void* w_base = nullptr;           // allocation that holds w
     uint8_t* mask_bank = nullptr;     // [Kcap][H][W]
     int Kcap = 0;
     int32_t* mask_id = nullptr;       // [Bmax]
@@ -168,11 +167,7 @@ static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, boo
         alloc((void**)&c->y, BN * sizeof(float2));
         alloc((void**)&c->work, BN * sizeof(float2));
         alloc((void**)&c->z, BN * sizeof(float));
-        {   // experiment knob PNP_STATE_SKEW_KB: w starts that many KiB into its allocation (z / w bank aliasing test)
-            const size_t skew = (size_t)env_int("PNP_STATE_SKEW_KB", 0) * 1024;
-            alloc((void**)&c->w_base, BN * sizeof(float) + skew);
-            if (c->w_base) c->w = (float*)((char*)c->w_base + skew);
-        }
+        alloc((void**)&c->w, BN * sizeof(float));
         alloc((void**)&c->x, BN * sizeof(float));
     }
     alloc((void**)&c->mask_id, (size_t)Bmax * sizeof(int32_t));
@@ -229,7 +224,7 @@ int pnp_ctx_destroy(pnp_ctx* c) {
     if (c->slice) slice256_destroy(c->slice);
     if (c->fs32) fused256s_destroy(c->fs32);
     if (c->fs64) fused256s_destroy(c->fs64);
-    void* ptrs[] = {c->y, c->work, c->z, c->w_base, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage, c->ssim_part,
+    void* ptrs[] = {c->y, c->work, c->z, c->w, c->x, c->mask_bank, c->mask_id, c->gt, c->acc, c->stage, c->ssim_part,
                     c->yd, c->workd, c->zd, c->wd, c->xd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -120,27 +120,16 @@ __device__ __forceinline__ void row_fft256(cxT<R> (&a)[16], const cxT<R>* twl, c
     fft256_tail<INV>(a);
 }
 
-// T (the row-transformed field of a slice pair, [256 rows][256 physical columns]) is stored BLOCKED:
-//   [row block 16][column block 256 / CBW][16 rows][CBW elements]          (t2_index)
-// A row workgroup's 16 rows are still one contiguous run (a permutation inside it); a wave access of a column kernel --
-// 4 rows of one column block -- becomes ONE contiguous piece (4 x CBW elements) instead of four row segments 2 KiB apart.
-// CBW = the physical columns a column workgroup covers per row: 32 for k_fcols (16 column pairs), 16 for k_fcols2.
-template <int CBW>
-PNP_HD size_t t2_index(int row, int pc) {
-    return (size_t)(row >> 4) * 4096 + (size_t)(pc / CBW) * (16 * CBW) + (row & 15) * CBW + (pc % CBW);
-}
-
 // PROX: see fused_pointwise.h
 constexpr int ROWS_LDS = 16 * XP + 272;      // c32 elements of LDS the row body needs (exchange regions + 16 x 17 twiddle rows)
 
-template <int CBW, typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 __device__ __forceinline__ void frows_body(const FRowArgsT<R>& p, const int bid, cxT<R>* lds) {
     using C = cxT<R>;
     struct alignas(16) U16 { char b[16]; };              // one 16-byte global / LDS access
     constexpr int EPU = 16 / (int)sizeof(C);             // elements per access: 2 (float) or 1 (double)
     constexpr int UPR = 256 / EPU;                       // accesses per row
     constexpr int NU = 16 * UPR / 256;                   // accesses per thread for the block's 16 rows
-    constexpr int APB = CBW / EPU;                       // accesses per row of a column block; storage order: [column block][row 16][APB]
     const int tid = threadIdx.x, g = tid >> 4, t = tid & 15;
     C* twl = lds + 16 * XP;                    // W256 table (read where used, not held in VGPRs)
     twl[17 * (tid >> 4) + (tid & 15)] = tw_table<R>()[((tid >> 4) * (tid & 15)) & 255];   // [t][k] = W256^(t k), rows of 17: conflict-free
@@ -154,8 +143,8 @@ __device__ __forceinline__ void frows_body(const FRowArgsT<R>& p, const int bid,
         const U16* src = reinterpret_cast<const U16*>(Tt);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int idx = tid + 256 * i, cb = idx / (16 * APB), row = (idx / APB) % 16, cu = idx % APB;
-            *reinterpret_cast<U16*>(&lds[row * RP + CBW * cb + EPU * cu]) = src[idx];
+            const int idx = tid + 256 * i, row = idx / UPR, c2 = idx % UPR;
+            *reinterpret_cast<U16*>(&lds[row * RP + EPU * c2]) = src[idx];
         }
         __syncthreads();
 #pragma unroll
@@ -187,16 +176,16 @@ __device__ __forceinline__ void frows_body(const FRowArgsT<R>& p, const int bid,
         U16* dst = reinterpret_cast<U16*>(Tt);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int idx = tid + 256 * i, cb = idx / (16 * APB), row = (idx / APB) % 16, cu = idx % APB;
-            dst[idx] = *reinterpret_cast<const U16*>(&lds[row * RP + CBW * cb + EPU * cu]);
+            const int idx = tid + 256 * i, row = idx / UPR, c2 = idx % UPR;
+            dst[idx] = *reinterpret_cast<const U16*>(&lds[row * RP + EPU * c2]);
         }
     }
 }
 
-template <int CBW, typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
+template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 __global__ __launch_bounds__(256) void k_frows(FRowArgsT<R> p) {
     __shared__ __attribute__((aligned(16))) cxT<R> lds[ROWS_LDS];
-    frows_body<CBW, R, HAS_INV, PROX, HAS_FWD, WRITE_X>(p, blockIdx.x, lds);
+    frows_body<R, HAS_INV, PROX, HAS_FWD, WRITE_X>(p, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -243,11 +232,12 @@ __device__ __forceinline__ void fcols_body(const FColArgs& p, const int bid, c32
         P[j] = mk(0.f, 0.f);
         Q[j] = mk(0.f, 0.f);
         if (valid) {
+            const c32* rowp = Tp + (t + 16 * j) * 256;
             if (self) {
-                P[j] = Tp[t2_index<32>(t + 16 * j, kl)];
+                P[j] = rowp[kl];
                 Q[j] = P[j];
             } else {
-                const float4 v = *reinterpret_cast<const float4*>(Tp + t2_index<32>(t + 16 * j, 2 * k2));
+                const float4 v = *reinterpret_cast<const float4*>(rowp + 2 * k2);
                 P[j] = mk(v.x, v.y);
                 Q[j] = mk(v.z, v.w);
             }
@@ -280,8 +270,9 @@ __device__ __forceinline__ void fcols_body(const FColArgs& p, const int bid, c32
     if (valid) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (self) Tp[t2_index<32>(t + 16 * j, kl)] = P[j];
-            else *reinterpret_cast<float4*>(Tp + t2_index<32>(t + 16 * j, 2 * k2)) = make_float4(P[j].x, P[j].y, Q[j].x, Q[j].y);
+            c32* rowp = Tp + (t + 16 * j) * 256;
+            if (self) rowp[kl] = P[j];
+            else *reinterpret_cast<float4*>(rowp + 2 * k2) = make_float4(P[j].x, P[j].y, Q[j].x, Q[j].y);
         }
     }
 }
@@ -311,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fmixed(FRowArgs pr, FColArgs pc, int nR
         const int rest = b - full * 25;                  // leftovers of the longer kind
         if (nR > full * 16) rid = full * 16 + rest; else cid = full * 9 + rest;
     }
-    if (rid >= 0) { if (rid < nR) frows_body<32, float, HAS_INV, PROX, HAS_FWD, WRITE_X>(pr, rid, lds); }
+    if (rid >= 0) { if (rid < nR) frows_body<float, HAS_INV, PROX, HAS_FWD, WRITE_X>(pr, rid, lds); }
     else if (cid < nC) fcols_body(pc, cid, lds);
 }
 
@@ -366,7 +357,7 @@ hipError_t fused256_prepare(Fused256* f, hipStream_t s, const float2* y, const u
 
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 static hipError_t launch_frows(hipStream_t s, int np, const FRowArgs& a) {
-    hipLaunchKernelGGL((k_frows<32, float, HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_frows<float, HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -595,12 +586,12 @@ __global__ __launch_bounds__(256) void k_fcols2(FCol2Args<R> p) {
     // element this lane moves: half `s` of the {column k2, column 256-k2} group (physical 2 k2 + s);
     // the self-mirrored columns 0 / 128 are single elements (physical 0 / 1) that both lanes read
     const int phys = self ? kl : 2 * (8 * m + kl) + s;
-    C* Tp = p.T + (size_t)pair * 65536;
+    C* Tp = p.T + (size_t)pair * 65536 + phys;
     C* twl = lds + 16 * CP;
     twl[17 * (tid >> 4) + (tid & 15)] = tw_table<R>()[((tid >> 4) * (tid & 15)) & 255];   // [t][k] = W256^(t k), rows of 17: conflict-free
     C a[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = valid ? Tp[t2_index<16>(t + 16 * j, phys)] : mk<R>((R)0, (R)0);
+    for (int j = 0; j < 16; ++j) a[j] = valid ? Tp[(t + 16 * j) * 256] : mk<R>((R)0, (R)0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const C other = self ? a[j] : dpp_swap1(a[j]);
@@ -628,7 +619,7 @@ __global__ __launch_bounds__(256) void k_fcols2(FCol2Args<R> p) {
         const C other = dpp_swap1(a[j]);
         const C xa = s ? other : a[j], xb = s ? a[j] : other;
         const C o = s ? repack_q(xa, xb) : repack_p(xa, xb);
-        if (valid && !(self && s)) Tp[t2_index<16>(t + 16 * j, phys)] = o;
+        if (valid && !(self && s)) Tp[(t + 16 * j) * 256] = o;
     }
 }
 
@@ -698,7 +689,7 @@ hipError_t fused256s_prepare(Fused256S<R>* f, hipStream_t s, const void* y, cons
 
 template <typename R, bool HAS_INV, int PROX, bool HAS_FWD, bool WRITE_X>
 static hipError_t launch_frows_t(hipStream_t s, int np, const FRowArgsT<R>& a) {
-    hipLaunchKernelGGL((k_frows<16, R, HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_frows<R, HAS_INV, PROX, HAS_FWD, WRITE_X>), dim3(np * 16), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 template <typename R>

@@ -10,10 +10,6 @@
 //             accesses are 16-byte {P,Q} elements in 128-byte row segments; the radix-2 partner
 //             is lane^8 (DPP row_ror:8)
 // HBM bytes per slice-iteration: 36 N, as at 256x256.
-//
-// T is stored BLOCKED: [pair][row block 64][column block 32][8 rows][16 complex] (t5_index).  A row workgroup's 8 rows are
-// still one contiguous 32 KiB run (a permutation inside it), and every wave access of the column kernel -- 8 rows x 128 bytes
-// of one column block -- is one contiguous 1 KiB block instead of eight 128-byte segments 4 KiB apart.
 #include "internal.h"
 #include "fused_layout.h"
 #include "fused_pointwise.h"
@@ -42,10 +38,6 @@ struct Fused512 {
 };
 
 constexpr int NN5 = 512 * 512;
-// element (row, physical column pc) of a pair's field T
-__host__ __device__ __forceinline__ size_t t5_index(int row, int pc) {
-    return (size_t)(row >> 3) * 4096 + (size_t)(pc >> 4) * 128 + (row & 7) * 16 + (pc & 15);
-}
 
 static inline ProxCoef to_coef5(const ProxParams& p) {
     ProxCoef c;
@@ -144,9 +136,9 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
     if (HAS_INV) {
         const float4* src = reinterpret_cast<const float4*>(Tt);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {                         // the row block's 32 KiB in storage order: [column block 32][row 8][8 float4]
-            const int idx = tid + 256 * i, cb = idx >> 6, row = (idx >> 3) & 7, c4 = idx & 7;
-            *reinterpret_cast<float4*>(&lds[row * RP5 + 16 * cb + 2 * c4]) = src[idx];
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 8, c2 = idx & 255;
+            *reinterpret_cast<float4*>(&lds[row * RP5 + 2 * c2]) = src[idx];
         }
         __syncthreads();
 #pragma unroll
@@ -189,8 +181,8 @@ __global__ __launch_bounds__(256) void k5_rows(FRowArgs p) {
         float4* dst = reinterpret_cast<float4*>(Tt);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, cb = idx >> 6, row = (idx >> 3) & 7, c4 = idx & 7;
-            dst[idx] = *reinterpret_cast<const float4*>(&lds[row * RP5 + 16 * cb + 2 * c4]);
+            const int idx = tid + 256 * i, row = idx >> 8, c2 = idx & 255;
+            dst[idx] = *reinterpret_cast<const float4*>(&lds[row * RP5 + 2 * c2]);
         }
     }
 }
@@ -249,12 +241,12 @@ __global__ __launch_bounds__(256) void k5_cols(F5ColArgs p) {
         P[j] = mk(0.f, 0.f);
         Q[j] = mk(0.f, 0.f);
         if (valid) {
-            // row t + 32 j = row block wv + 4 j, row tq inside it: the wave reads ONE 1 KiB block of the column block m
+            const c32* rowp = Tp + (size_t)(t + 32 * j) * 512;
             if (self) {
-                P[j] = Tp[t5_index(t + 32 * j, kl)];
+                P[j] = rowp[kl];
                 Q[j] = P[j];
             } else {
-                const float4 v = *reinterpret_cast<const float4*>(Tp + t5_index(t + 32 * j, 2 * k2));
+                const float4 v = *reinterpret_cast<const float4*>(rowp + 2 * k2);
                 P[j] = mk(v.x, v.y);
                 Q[j] = mk(v.z, v.w);
             }
@@ -281,8 +273,9 @@ __global__ __launch_bounds__(256) void k5_cols(F5ColArgs p) {
     if (valid) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (self) Tp[t5_index(t + 32 * j, kl)] = P[j];
-            else *reinterpret_cast<float4*>(Tp + t5_index(t + 32 * j, 2 * k2)) = make_float4(P[j].x, P[j].y, Q[j].x, Q[j].y);
+            c32* rowp = Tp + (size_t)(t + 32 * j) * 512;
+            if (self) rowp[kl] = P[j];
+            else *reinterpret_cast<float4*>(rowp + 2 * k2) = make_float4(P[j].x, P[j].y, Q[j].x, Q[j].y);
         }
     }
 }
