@@ -1,21 +1,17 @@
 #!/bin/bash
-# Run ON THE GPU BOX: everything DESIGN.md quotes -- the -m gpu suite, the rocprofv3 collections of every
-# configuration, the bench lines.  Afterwards, in the build container:
-#   python profiles/summarize.py r02 slice_cnc fused_cnc_seq fused_cnc_2q slice_l1 fused_l1_seq fused512_cnc_seq fused512_cnc fused_f64_seq fused_f64_2q fused_f64_chunk fused_f64_default generic_cnc
+# Run ON THE GPU BOX: everything DESIGN.md quotes for round 3 -- the -m gpu suite, the rocprofv3 collections of the
+# configurations whose kernels changed this round, the bench lines, the PnP lines, a marker trace.  Afterwards, in the build
+# container:   python profiles/summarize.py r03 slice_cnc slice_l1 generic_cnc
+# (the two-launch kernels are unchanged since round 2: their rocprof_r02_* files stay the evidence)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/final/pytest.log
 tail -4 gpurun_out/final/pytest.log
 bash profiles/collect.sh slice_cnc
-PNP_SLICE=0 PNP_FUSED_STREAMS=1 bash profiles/collect.sh fused_cnc_seq
-PNP_SLICE=0 bash profiles/collect.sh fused_cnc_2q
 bash profiles/collect.sh slice_l1 --solver l1
-PNP_SLICE=0 PNP_FUSED_STREAMS=1 bash profiles/collect.sh fused_l1_seq --solver l1
-PNP_FUSED_STREAMS=1 bash profiles/collect.sh fused512_cnc_seq --size 512 --batch 256
-bash profiles/collect.sh fused512_cnc --size 512 --batch 256
-PNP_FUSED_STREAMS=1 PNP_FUSED_CHUNK=-1 bash profiles/collect.sh fused_f64_seq --precision f64
-PNP_FUSED_CHUNK=-1 bash profiles/collect.sh fused_f64_2q --precision f64
-PNP_FUSED_STREAMS=1 bash profiles/collect.sh fused_f64_chunk --precision f64
-bash profiles/collect.sh fused_f64_default --precision f64
 bash profiles/collect.sh generic_cnc --generic
 bash profiles/run_bench_lines.sh
+# roctx ranges of the loop entry points in a marker trace (pnp_admm_cnc_run around the k_slice launch)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_markers -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_markers.log 2>&1)
+find gpurun_out/prof_markers -name '*_kernel_trace.csv' -delete
+find gpurun_out/prof_markers -name '*marker*' | head -3

@@ -3,18 +3,21 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/bench_lines; mkdir -p $O
 export PNP_BENCH_CACHE=/tmp/pnp_bench_inputs
-python3 bench.py > $O/default_100.json 2>/dev/null                                         # full line incl. CPU baselines
+python3 bench.py > $O/default_100.json 2>/dev/null                                         # full line incl. CPU baselines, parity and f64 records
+python3 bench.py --steps 20 --warmup 5 > $O/driver_shape_full.json 2>/dev/null                 # the driver's command line
 for i in 1 2 3; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/driver_shape_$i.json 2>/dev/null; done
-for i in 1 2 3; do PNP_SLICE=0 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/driver_shape_fused_$i.json 2>/dev/null; done
 PNP_SLICE=0 python3 bench.py --no-cpu-baseline > $O/fused_100.json 2>/dev/null
 python3 bench.py --solver l1 --no-cpu-baseline > $O/l1_100.json 2>/dev/null
 python3 bench.py --precision f64 --steps 50 --warmup 5 --no-cpu-baseline > $O/f64_50.json 2>/dev/null
-python3 bench.py --precision f64 --generic --steps 20 --warmup 2 --no-cpu-baseline > $O/f64_generic_20.json 2>/dev/null
 python3 bench.py --size 512 --batch 256 --no-cpu-baseline > $O/size512_100.json 2>/dev/null
 python3 bench.py --size 512 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/size512_driver_shape.json 2>/dev/null
 python3 bench.py --generic --no-cpu-baseline > $O/generic_100.json 2>/dev/null
+PNP_GENERIC_STOCKHAM=1 python3 bench.py --generic --no-cpu-baseline > $O/generic_stockham_100.json 2>/dev/null
 python3 bench.py --gpus 2 --rehearse-gloo --steps 20 --warmup 5 > $O/gpus2_rehearsal.json 2>/dev/null
+PNP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/rccl_one_rank.json 2>/dev/null
 python3 bench.py --batch 1024 --no-cpu-baseline > $O/batch1024_100.json 2>/dev/null
-for f in $O/*.json; do echo "$(basename $f): $(grep -o '"value": [0-9.]*' $f | head -1) $(grep -o '"ms_per_step": [0-9.]*' $f) $(grep -o '"frac_measured": [0-9.a-z]*' $f)"; done
-python3 bench_pnp.py --model ffdnet_gray --batch 512 --steps 6 --warmup 2 --channels-last > $O/pnp_ffdnet.json 2>/dev/null; tail -1 $O/pnp_ffdnet.json | cut -c1-400
-python3 bench_pnp.py --model drunet_gray --batch 512 --steps 2 --warmup 1 --channels-last > $O/pnp_drunet.json 2>/dev/null; tail -1 $O/pnp_drunet.json | cut -c1-400
+for f in $O/*.json; do echo "$(basename $f): $(grep -o '"value": [0-9.]*' $f | head -1) $(grep -o '"ms_per_step": [0-9.]*' $f | head -1) $(grep -o '"frac_measured": [0-9.a-z]*' $f | head -1)"; done
+python3 bench_pnp.py --model ffdnet_gray --batch 512 --steps 6 --warmup 2 > $O/pnp_ffdnet.json 2>/dev/null; tail -1 $O/pnp_ffdnet.json | cut -c1-300
+python3 bench_pnp.py --model drunet_gray --batch 512 --steps 2 --warmup 1 > $O/pnp_drunet.json 2>/dev/null; tail -1 $O/pnp_drunet.json | cut -c1-300
+python3 bench_pnp.py --model drunet_gray --size 512 --batch 64 --cnn-batch 16 --steps 2 --warmup 1 > $O/pnp_drunet512.json 2>/dev/null; tail -1 $O/pnp_drunet512.json | cut -c1-300
+python3 bench_pnp.py --model ffdnet_gray --batch 64 --steps 3 --warmup 1 --gpus 2 --rehearse-gloo > $O/pnp_ffdnet_gpus2_rehearsal.json 2>/dev/null; tail -1 $O/pnp_ffdnet_gpus2_rehearsal.json | cut -c1-200

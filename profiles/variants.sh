@@ -5,6 +5,7 @@
 # developer knob of pnp_admm_cnc_mri_amd/_lib.py).
 #
 #   build (here or on the box; hipcc cross-compiles):   bash profiles/variants.sh build <file.hip> <name> "<-D flags>"
+#   commit (build container: needs .git): the library of an earlier commit:   bash profiles/variants.sh commit <sha> <name>
 #   run   (on the GPU box):                              bash profiles/variants.sh run "<bench args>" <reps> <name> [<name> ...]
 #          "base" names the in-tree library.  Prints value (it/s) per arm and repetition.
 #   prof  (on the GPU box): phase clocks of the slice kernel at batch 64 and 512:  bash profiles/variants.sh prof <name> ...
@@ -25,6 +26,13 @@ build)
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib_$NAME.so $OBJS -ldl
   echo "built $V/lib_$NAME.so [$FLAGS]"
+  ;;
+commit)
+  SHA=$2; NAME=$3
+  rm -rf $R/build/ab/$NAME && mkdir -p $R/build/ab/$NAME
+  git -C $R archive $SHA pnp_admm_cnc_mri_amd/csrc include | tar -x -C $R/build/ab/$NAME
+  make -C $R/build/ab/$NAME/pnp_admm_cnc_mri_amd/csrc -j4 OUT=$V/lib_$NAME.so > /dev/null
+  echo "built $V/lib_$NAME.so from $SHA"
   ;;
 run)
   ARGS=$2; REPS=$3; shift 3
