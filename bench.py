@@ -165,6 +165,16 @@ def launch_ranks(n, timeout_s, script=None):
     return rc
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner when its
+    process group comes up), so everything that is not the line goes to stderr: file descriptor 1 is pointed at stderr for the
+    rest of the process and the returned file object is the only way to the real stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -196,6 +206,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         args.gpus = world
+    out = claim_stdout()
 
     import torch
     import pnp_admm_cnc_mri_amd as P
@@ -417,7 +428,8 @@ def main():
                 line['cpu_baseline_all_cores'] = {'error': repr(e)}
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line), flush=True)
+        out.write(json.dumps(line) + '\n')
+        out.flush()
     eng.close()
     if dist is not None:
         dist.barrier()

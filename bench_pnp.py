@@ -54,6 +54,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = 0 if args.rehearse_gloo else int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    import bench
+    out = bench.claim_stdout()                       # ONE JSON line on stdout, whatever RCCL / MIOpen print
 
     import torch
     import pnp_admm_cnc_mri_amd as P
@@ -150,7 +152,7 @@ def main():
         den_flop = 2.0 * flop_per_call * B                              # two D(.) per iteration, every slice
         den_gflops = den_flop / (cnn_ms * 1e-3) / 1e9
         alg_bytes = 57.0 * H * W * B
-        print(json.dumps({
+        out.write(json.dumps({
             'metric': 'PNP_ADMM_CNC_D iterations/sec on %dx%d slices (%s)' % (H, W, args.model),
             'value': world * K / wall * (B / 512.0), 'unit': 'it/s (512-slice batches)', 'n_gpus': world, 'steps': K,
             'warmup': args.warmup, 'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -169,7 +171,8 @@ def main():
                          'roofline': {'bound': 'mfma_f32', 'achieved': den_gflops, 'peak': F32_MATRIX_PEAK_GFLOPS, 'unit': 'GFLOP/s',
                                       'frac': den_gflops / F32_MATRIX_PEAK_GFLOPS},
                          'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)'},
-            'x_finite': bool(torch.isfinite(x).all())}), flush=True)
+            'x_finite': bool(torch.isfinite(x).all())}) + '\n')
+        out.flush()
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -58,8 +58,9 @@ int pnp_sync(pnp_ctx* ctx);
 int pnp_set_fast_path(pnp_ctx* ctx, int enable);
 /* Scheduling of the fused loops (results are bit-identical for every setting):
  *   queues          1..4 HIP queues the batch is split over (default 2; forked/joined on the ctx stream)
- *   mixed_launches  256x256: row workgroups of one half of a part share each launch with the column
- *                   workgroups of its other half (default 1)
+ *   mixed_launches  256x256 two-launch path: row workgroups of one half of a part share each launch with the column
+ *                   workgroups of its other half (default 0: retired in round 2 -- measured within noise of plain row and
+ *                   column launches on two queues; kept as a knob)
  *   chunk           >0: a queue runs all iterations on `chunk` slices before its next chunk; 0 (default): the path's own
  *                   default -- at 512x512 and for the double-precision 256x256 engine the chunks go round-robin to 4 queues
  *                   (16 resp. 24 slices each with queues >= 2; 48 resp. 96 on one queue), so the chunks in flight fit the
@@ -148,13 +149,14 @@ int pnp_metrics(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_d
  * valid region, gray images), computed in double on the device.  x_dev = NULL: the ctx-owned x. */
 int pnp_ssim(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_device, double* ssim_host);
 
-/* ---- fp64 validation context ---------------------------------------------------------------
+/* ---- double-precision context -------------------------------------------------------------
  * The same loops (pnp_init_state, pnp_admm_l1_run, pnp_admm_cnc_run) with every buffer and every
- * arithmetic step in double / complex128 on the generic kernels: the reference itself runs in
- * float64 (S4:109 `w = np.zeros(..., dtype=np.float64)`), and its committed CNC presets amplify
- * fp32 round-off ~1.08x per iteration, so this is the mode in which 100-iteration CNC runs meet
- * 1e-5 end to end.  Not a throughput path; the step-wise / operator entry points are float-only
- * and return PNP_E_STATE on such a context. */
+ * arithmetic step in double / complex128: the reference itself runs in float64 (S4:109
+ * `w = np.zeros(..., dtype=np.float64)`), and its committed CNC presets amplify fp32 round-off
+ * ~1.08x per iteration, so this is the mode in which 100-iteration CNC runs meet 1e-5 end to end.
+ * 256x256 runs on the fused two-launch kernels in double (a throughput path: ~2500 batched
+ * iterations/s at 512 slices); other shapes on the generic kernels in double.
+ * The step-wise / operator entry points are float-only and return PNP_E_STATE on such a context. */
 int pnp_ctx_create_f64(int device, int H, int W, int Bmax, pnp_ctx** out);
 /* y: [B][H][W] complex128 (interleaved doubles); masks as pnp_upload_problem. */
 int pnp_upload_problem_f64(pnp_ctx* ctx, const double* y, const uint8_t* mask_bank,
@@ -169,8 +171,11 @@ int pnp_timer_start(pnp_ctx* ctx);
 int pnp_timer_stop(pnp_ctx* ctx, float* elapsed_ms);    /* records, synchronises, returns ms */
 
 /* ---- introspection ------------------------------------------------------------------------ */
-/* launches per batched ADMM iteration on the current path and schedule, and which path
- * ("generic" | "fused") the loops take for the uploaded problem */
+/* launches per batched ADMM iteration on the current path and schedule (0 = the iterations of a call are a
+ * loop inside ONE launch), and which kernel family the loops take for the uploaded problem:
+ *   "slice"   256x256 float, batches of >= 64 slices: one workgroup keeps a slice in registers for the whole run
+ *   "fused"   two launches per iteration (256x256 float / double, 512x512 float)
+ *   "generic" three launches per iteration (any H, W in {256, 512}; pnp_set_fast_path(ctx, 0)) */
 int         pnp_kernels_per_iteration(pnp_ctx* ctx);
 const char* pnp_path_name(pnp_ctx* ctx);
 

@@ -458,7 +458,9 @@ def test_bench_runs_its_collectives_on_rccl_with_one_rank():
     r = subprocess.run(base, env=dict(env_, PNP_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
+    # the contract is ONE line on stdout: RCCL's version banner (it prints one when the process group comes up) must not be there
+    assert len(r.stdout.decode().strip().splitlines()) == 1, r.stdout.decode()[:400]
+    j = json.loads(r.stdout.decode().strip())
     assert j['n_gpus'] == 1 and j['gather_ms'] is not None and j['gather_ms'] > 0 and j['x_finite']
     assert j['config']['path'] == 'slice'
     r1 = subprocess.run(base, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
