@@ -54,3 +54,18 @@ for r in range(8):
         row.append(np.median(d))
     it = np.median(ph_all[sel, :, 5] - prev_all[sel])
     print('  %d: ' % r + ' '.join('%6.2f' % v for v in row) + ' | %6.2f' % it)
+
+# second round (blocks 256..): does its pace converge to the first round's?  per-iteration time by iteration index
+if B > 256:
+    d2 = (ph_all[256:, :, 5] - prev_all[256:])
+    d1 = (ph_all[:256, :, 5] - prev_all[:256])
+    idx = list(range(0, min(iters, 12))) + list(range(max(12, iters - 4), iters))
+    print('iteration index            :', idx)
+    print('first round  (median, us)  :', np.round(np.median(d1, axis=0)[idx], 1))
+    print('second round (median, us)  :', np.round(np.median(d2, axis=0)[idx], 1))
+    rows2 = ph_all[256:, :, 5] - ph_all[256:, :, 4]
+    rows1 = ph_all[:256, :, 5] - ph_all[:256, :, 4]
+    print('row phase first / second round (median over all iterations): %.2f / %.2f us' % (np.median(rows1), np.median(rows2)))
+    st = raw_all[256:, 0] - raw_all[:, 0].min()
+    print('second-round start times: min %.0f median %.0f max %.0f us; first-round end: min %.0f median %.0f max %.0f' % (
+        st.min(), np.median(st), st.max(), (raw_all[:256, -1] - raw_all[:, 0].min()).min(), np.median(raw_all[:256, -1] - raw_all[:, 0].min()), (raw_all[:256, -1] - raw_all[:, 0].min()).max()))
