@@ -59,6 +59,7 @@ struct SliceArgs {
     const uint32_t* Ms;       // [B][16]
     int first, B, iters;      // slices [first, first + B) of the arrays; iterations of this launch
     int slice_xor;            // experiment knob (PNP_SLICE_XOR): workgroup b takes slice b ^ slice_xor (both below B)
+    int flip;                 // workgroup b takes slice B - 1 - b: the launch starts with the slices the previous launch ended with
     float scale, c;
     ProxCoef prox;
     long long* prof;          // phase clock dump of a -DSLICE_PROF build (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
@@ -553,7 +554,8 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     c32* wreg = lds + wv * WREG;
     __syncthreads();
     for (int sb = blockIdx.x; sb < p.B; sb += gridDim.x) {
-        const int slice = p.first + (((sb ^ p.slice_xor) < p.B) ? (sb ^ p.slice_xor) : sb);
+        const int sx = ((sb ^ p.slice_xor) < p.B) ? (sb ^ p.slice_xor) : sb;
+        const int slice = p.first + (p.flip ? p.B - 1 - sx : sx);
         const size_t so = (size_t)slice * 65536;
         SliceBufs b;
         b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + so, 65536 * 4);
@@ -671,6 +673,7 @@ hipError_t slice256_state_order(hipStream_t s, float* z, float* w, int B, bool t
 // ------------------------------------------------------------------------------------------
 struct Slice256 {
     int Bmax = 0, cus = 0;
+    int flip = 0;                            // direction of the next multi-round launch
     c32* Yh = nullptr;
     uint32_t* Mh = nullptr;
     c32* Ys = nullptr;
@@ -759,6 +762,7 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
     a.prof = nullptr;
     a.slice_xor = 0;
+    a.flip = 0;
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     a.slice_xor = env_int("PNP_SLICE_XOR", 0);
     if (a.slice_xor < 0 || (B & (B - 1)) != 0 || a.slice_xor >= B) a.slice_xor = 0;      // a permutation only for power-of-two batches
@@ -784,6 +788,10 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
             a.prof = d_prof;
         }
     }
+    // A batch larger than the chip runs in rounds (one slice per compute unit at a time), and the slices of the LAST round
+    // are the ones the Infinity Cache still holds when the call returns: every other call walks the batch backwards, so that
+    // a following call starts on warm data (DESIGN.md 4.1, round hand-over).  Slices are independent: results do not change.
+    if (!prof_path && B > slice256_cus(f) && env_int("PNP_SLICE_FLIP", 1)) { a.flip = f->flip; f->flip ^= 1; }
     hipError_t e = hipSuccess;
     if (queues > 1) {
         if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);
