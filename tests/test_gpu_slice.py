@@ -192,3 +192,63 @@ def test_chip_filling_run_matches_the_two_launch_path(P, monkeypatch):
     finally:
         for e in engs.values():
             e.close()
+
+
+def test_state_order_is_private_to_the_slice_path(P, golden_inputs, monkeypatch):
+    """Between slice-resident runs the ctx keeps z / w in the kernel's own order (slice_layout.h, sl_state_index); everything
+    else must keep seeing natural [B][H][W]: get_state in the middle of a run, set_state of one array only, a switch to the
+    generic kernels and back, a new (smaller) problem on the same context."""
+    B = 70
+    masks, mid, ys = _problem(golden_inputs, B)
+    args = (0.45, 0.5, 0.05, 64)
+    monkeypatch.setenv('PNP_SLICE', '0')
+    with P.Engine(256, 256, Bmax=B) as ref:
+        ref.upload(ys, masks, mid)
+        ref.init_state()
+        ref.admm_cnc(3, *args)
+        z3r, w3r = ref.get_state()
+        ref.admm_cnc(2, *args)
+        x5r = ref.x()
+        z5r, w5r = ref.get_state()
+    monkeypatch.delenv('PNP_SLICE')
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.upload(ys, masks, mid)
+        assert eng.path_name == 'slice'
+        eng.init_state()
+        eng.admm_cnc(3, *args)
+        z3, w3 = eng.get_state()                                   # natural order out of a sliced state
+        assert np.abs(z3 - z3r).max() <= 2e-5 and np.abs(w3 - w3r).max() <= 2e-5
+        eng.admm_cnc(2, *args)                                     # ... and the run goes on from it
+        x5 = eng.x()
+        z5, w5 = eng.get_state()
+        assert np.abs(x5 - x5r).max() <= 2e-5 and np.abs(z5 - z5r).max() <= 2e-5 and np.abs(w5 - w5r).max() <= 2e-5
+        # one array replaced while the other stays: the untouched one must come back unchanged, in natural order
+        eng.admm_cnc(1, *args)
+        z6, w6 = eng.get_state()
+        eng.admm_cnc(1, *args)                                     # state is sliced again
+        eng.set_state(z=z3)
+        zb, wb = eng.get_state()
+        z7, w7 = None, None
+        assert np.array_equal(zb, z3)
+        eng.set_state(z=z6, w=w6)
+        eng.admm_cnc(1, *args)
+        z7, w7 = eng.get_state()
+        assert not np.array_equal(wb, w6) and np.isfinite(wb).all()
+        # the generic kernels continue from a sliced state: one generic iteration == one slice-resident iteration (round-off)
+        eng.set_state(z=z6, w=w6)
+        eng.admm_cnc(1, *args)                                     # slice path: state sliced
+        eng.set_state(z=z6, w=w6)
+        eng.set_fast_path(0)
+        eng.admm_cnc(1, *args)
+        zg, wg = eng.get_state()
+        assert eng.path_name == 'generic' and np.abs(zg - z7).max() <= 2e-5 and np.abs(wg - w7).max() <= 2e-5
+        eng.set_fast_path(1)
+        eng.admm_cnc(1, *args)                                     # back on the slice path from a natural state
+        assert eng.path_name == 'slice' and np.isfinite(eng.x()).all()
+        # a smaller problem on the same context after a sliced state (conversion happens under the old batch size)
+        eng.upload(ys[:3], masks, mid[:3])
+        eng.init_state()
+        eng.admm_cnc(4, *args)
+        xs = eng.x()
+    for b in range(3):
+        assert rel_l2(xs[b], O.admm_cnc(ys[b].astype(np.complex128), masks[mid[b]], 4)) <= 2e-6
