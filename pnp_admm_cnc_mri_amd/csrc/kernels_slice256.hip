@@ -35,6 +35,9 @@
 #include <stdlib.h>
 #include <vector>
 
+#ifndef SLICE_EARLY
+#define SLICE_EARLY 1       // set 0 of the row phase: its first z / w accesses go out between the two passes of T2 (0: at the start of the phase; +0.8 % at 100 steps)
+#endif
 #ifndef SLICE_YH_AUX
 #define SLICE_YH_AUX 0      // cache policy bits of the Hermitian-table loads (experiment knob: 2 = nt)
 #endif
@@ -324,16 +327,23 @@ __device__ __forceinline__ void store_x_natural(const SliceBufs& b, float scale,
 }
 
 // all four register sets of a wave; loads of set s + 1 are in flight during the transforms around them
-template <bool HAS_INV, int PROX, bool HAS_FWD>
+template <int PROX> constexpr int row_pf() { return (PROX == 3) ? 8 : SLICE_PF; }
+// the first accesses of set 0, issued by the caller ahead of the phase (SLICE_EARLY: between the two passes of T2)
+template <int PROX, bool HAS_INV>
+__device__ __forceinline__ void row_phase_prefetch(const SliceBufs& b, RowLoads& L, int wv, int lane) {
+    issue_row_loads<PROX, HAS_INV, 0, row_pf<PROX>()>(b, L, row_set_offset(0, wv), 2048 * (lane >> 4) + 16 * (lane & 15));
+}
+template <bool HAS_INV, int PROX, bool HAS_FWD, bool PRELOADED = false>
 __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32 (&F)[SL_SETS][16],
-                                          c32* wreg, const c32* twl, int wv, int lane) {
+                                          c32* wreg, const c32* twl, int wv, int lane, RowLoads* pre = nullptr) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
     const int voff = 2048 * g + 16 * t;
     // PF accesses of the next set are fetched ahead across the transforms; the rest when the set's pointwise phase starts
-    constexpr int PF = (PROX == 3) ? 8 : SLICE_PF;
+    constexpr int PF = row_pf<PROX>();
     RowLoads L;
-    issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, row_set_offset(0, wv), voff);
+    if (PRELOADED) L = *pre;
+    else issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, row_set_offset(0, wv), voff);
 #pragma unroll
     for (int set = 0; set < SL_SETS; ++set) {
         c32 (&a)[16] = F[set];
@@ -585,10 +595,18 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
             __syncthreads();
             SL_STAMP();
             t2_pass<0>(G, F, lds, wv, opaque(lane));
+#if SLICE_EARLY
+            RowLoads L0;
+            row_phase_prefetch<PROX, true>(b, L0, wv, opaque(lane));
+#endif
             t2_pass<1>(G, F, lds, wv, opaque(lane));
             SL_STAMP();
             const int u_first = (it == 0);
+#if SLICE_EARLY
+            row_phase<true, PROX, true, true>(b, p.prox, p.scale, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane), &L0);
+#else
             row_phase<true, PROX, true>(b, p.prox, p.scale, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane));
+#endif
             SL_STAMP();
         }
         __syncthreads();
