@@ -589,7 +589,11 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
             SL_STAMP();                           // wave 0's wait for the slowest wave of the row phase ends here
             t1_pass<0>(F, G, lds, wv, opaque(lane));
             t1_pass<1>(F, G, lds, wv, opaque(lane));
+#ifdef SLICE_PROF_CLOCK                      // diagnostic build: this slot carries the SHADER clock (s_memtime) instead of the 100 MHz wall clock
+            if (prof) *prof++ = (long long)__builtin_readcyclecounter();
+#else
             SL_STAMP();
+#endif
             col_phase(b, p.c, G, wreg, lds + SL_YS, twl, wv, opaque(lane));
             SL_STAMP();
             __syncthreads();

@@ -59,13 +59,33 @@ for r in range(8):
 if B > 256:
     d2 = (ph_all[256:, :, 5] - prev_all[256:])
     d1 = (ph_all[:256, :, 5] - prev_all[:256])
-    idx = list(range(0, min(iters, 12))) + list(range(max(12, iters - 4), iters))
+    idx = list(range(0, min(iters, 12))) + list(range(12, max(12, iters - 4), max(1, (iters - 16) // 16))) + list(range(max(12, iters - 4), iters))
     print('iteration index            :', idx)
     print('first round  (median, us)  :', np.round(np.median(d1, axis=0)[idx], 1))
     print('second round (median, us)  :', np.round(np.median(d2, axis=0)[idx], 1))
+    print('first round, even / odd blocks:', np.round(np.median(d1[0::2], axis=0)[idx], 1), '/', np.round(np.median(d1[1::2], axis=0)[idx], 1))
+    for k, nm in ((1, 'T1'), (2, 'columns'), (4, 'T2'), (5, 'rows')):
+        dk = ph_all[:256, :, k] - ph_all[:256, :, k - 1]
+        print('first round %-8s by index :' % nm, np.round(np.median(dk, axis=0)[idx], 2))
+        dk2 = ph_all[256:, :, k] - ph_all[256:, :, k - 1]
+        print('second round %-7s by index :' % nm, np.round(np.median(dk2, axis=0)[idx], 2))
     rows2 = ph_all[256:, :, 5] - ph_all[256:, :, 4]
     rows1 = ph_all[:256, :, 5] - ph_all[:256, :, 4]
     print('row phase first / second round (median over all iterations): %.2f / %.2f us' % (np.median(rows1), np.median(rows2)))
     st = raw_all[256:, 0] - raw_all[:, 0].min()
     print('second-round start times: min %.0f median %.0f max %.0f us; first-round end: min %.0f median %.0f max %.0f' % (
         st.min(), np.median(st), st.max(), (raw_all[:256, -1] - raw_all[:, 0].min()).min(), np.median(raw_all[:256, -1] - raw_all[:, 0].min()), (raw_all[:256, -1] - raw_all[:, 0].min()).max()))
+
+# -DSLICE_PROF_CLOCK build: slot k = 1 of every iteration holds the shader clock (s_memtime): MHz the compute unit ran at, by iteration
+if len(sys.argv) > 2 and sys.argv[2] == 'clock':
+    cyc = ph_all[:, 1:, 1] - ph_all[:, :-1, 1]                 # shader cycles between the T1 stamps of consecutive iterations (x 100: undo the /100)
+    wall = ph_all[:, 1:, 5] - ph_all[:, :-1, 5]                # us between the ends of consecutive iterations
+    mhz = cyc * 100.0 / wall
+    step = max(1, (iters - 1) // 24)
+    ii = list(range(0, iters - 1, step))
+    print('iteration index               :', ii)
+    print('first round  clock (MHz)      :', np.round(np.median(mhz[:256], axis=0)[ii]))
+    if B > 256:
+        print('second round clock (MHz)      :', np.round(np.median(mhz[256:], axis=0)[ii]))
+    print('first round  iteration (us)   :', np.round(np.median(wall[:256], axis=0)[ii], 1))
+    print('first round  cycles/iteration :', np.round(np.median(cyc[:256] * 100.0, axis=0)[ii]))
