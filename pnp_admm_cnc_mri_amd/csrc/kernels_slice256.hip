@@ -38,6 +38,12 @@
 #ifndef SLICE_EARLY
 #define SLICE_EARLY 1       // set 0 of the row phase: its first z / w accesses go out between the two passes of T2 (0: at the start of the phase; +0.8 % at 100 steps)
 #endif
+#ifndef SLICE_PRIOSWAP
+#define SLICE_PRIOSWAP 1    // the two waves of a SIMD trade issue priority between register sets of the wave-local phases (0: never)
+#endif
+#ifndef SLICE_PRIOMASK
+#define SLICE_PRIOMASK 6    // bit s: the older wave of each SIMD pair (waves 0-3) has the higher priority during register set s
+#endif
 #ifndef SLICE_YH_AUX
 #define SLICE_YH_AUX 0      // cache policy bits of the Hermitian-table loads (experiment knob: 2 = nt)
 #endif
@@ -87,6 +93,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef SLICE_SYNC_SCHED_BARRIER             // experiment knob: also stop the scheduler here (measured slower)
     __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// The two waves of a SIMD (w and w + 4) run the same program; left alone, the older one wins the issue arbitration all phase
+// long, reaches the barrier 2-3 us early and leaves its partner alone on the SIMD, where one wave cannot hide its own LDS
+// latencies.  Trading the priority between register sets keeps them side by side: +2-3 % on a quarter-full chip, +1-1.5 % on a
+// full one, for every pattern that changes hands at least once (profiles/variants_r03.log; 0110 = younger, older, older, younger)
+__device__ __forceinline__ void prio_set(int wv, int set) {
+#if SLICE_PRIOSWAP
+    const bool older_high = (SLICE_PRIOMASK >> set) & 1;              // compile-time per set
+    if (set == 0 || (((SLICE_PRIOMASK >> set) ^ (SLICE_PRIOMASK >> (set - 1))) & 1)) {      // only where the pattern changes
+        if ((wv < 4) == older_high) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
 #endif
 }
 
@@ -347,6 +366,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
 #pragma unroll
     for (int set = 0; set < SL_SETS; ++set) {
         c32 (&a)[16] = F[set];
+        prio_set(wv, set);
         const int soff = row_set_offset(set, wv);
         if (HAS_INV) {
 #ifndef SLICE_ABLATE_ROWFFT
@@ -527,6 +547,7 @@ __device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G
 #pragma unroll
     for (int set = 0; set < SL_SETS; ++set) {
         c32 (&a)[16] = G[set];
+        prio_set(wv, set);
         group_fft256<false>(a, twl, region, t);                   // a[j] = spectrum at k1 = t + 16 j, k2 = c
         if (set == 0 && wv == 0 && g == 0) {
             // packed column: a = A + i B, A / B = spectra of the real columns k2 = 0 / 128; split with the mirror k1 -> -k1
