@@ -639,28 +639,76 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// operand tables (once per uploaded problem): one block per (k2 = 0..128, slice)
+// operand tables (once per uploaded problem): one block per (tile of 16 columns k2, slice); tile 8 = the column k2 = 128.
+// The tile of y (and of the mask) and its mirror image (rows -k1, columns -k2) go through LDS, so that global memory is
+// read in 128-byte row segments and every table block is written in its own contiguous order.  (Until round 3 a block held
+// ONE column and its 256 threads read y with a 2 KiB stride: 2.3 GB fetched for 0.4 GB of input at 512 slices, 350 us.)
+// Arithmetic = hermitian_entry_t (fused_layout.h): unsampled entries are selected away, never multiplied.
 // ------------------------------------------------------------------------------------------
+constexpr int SP_P = 17;                       // tile pitch (columns + 1)
 __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
                                                   c32* Yh, uint32_t* Mh, c32* Ys, uint32_t* Ms) {
-    __shared__ int codes[256];
-    const int k1 = threadIdx.x, j = k1 >> 4, t = k1 & 15;
-    const int k2 = blockIdx.x, slice = blockIdx.y;
+    __shared__ c32 yd[256 * SP_P], ym[256 * SP_P];           // direct tile [row][c], mirror tile [row][c] = y[row][-(16 m + c)]
+    __shared__ uint8_t md[256 * SP_P], mm[256 * SP_P];
+    const int tid = threadIdx.x, m = blockIdx.x, slice = blockIdx.y;
     const int mid = mask_id ? mask_id[slice] : 0;
-    c32 yh;
-    int code;
-    hermitian_entry_t<float>(y + (size_t)slice * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh, code);
-    codes[k1] = code;
-    const int c = k2 & 127, set = c >> 5, wv = (c & 31) >> 2, lane = 16 * (c & 3) + t;
-    if (k2 < 128) Yh[yh3_index(slice, set, j, wv, lane)] = yh;
-    else          Ys[(size_t)slice * 256 + k1] = yh;
+    const c32* ys = y + (size_t)slice * 65536;
+    const uint8_t* ms = mask_bank + (size_t)mid * 65536;
+    const int ncol = (m == 8) ? 1 : 16;                        // tile 8: k2 = 128 alone (its own mirror column)
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
+        if (c < ncol) {
+            const int k2 = 16 * m + c, k2m = (256 - k2) & 255;
+            yd[r * SP_P + c] = ys[r * 256 + k2];
+            md[r * SP_P + c] = ms[r * 256 + k2];
+            ym[r * SP_P + c] = ys[r * 256 + k2m];
+            mm[r * SP_P + c] = ms[r * 256 + k2m];
+        }
+    }
     __syncthreads();
-    if (k1 < 16) {
+    auto entry = [&](int k1, int c, c32& yh) -> int {
+        const int r2 = (256 - k1) & 255;
+        const int m1 = md[k1 * SP_P + c] != 0, m2 = mm[r2 * SP_P + c] != 0;
+        const c32 y1 = yd[k1 * SP_P + c], y2 = ym[r2 * SP_P + c];
+        yh = mk<float>(0.5f * ((m1 ? y1.x : 0.f) + (m2 ? y2.x : 0.f)), 0.5f * ((m1 ? y1.y : 0.f) - (m2 ? y2.y : 0.f)));
+        return m1 + m2;
+    };
+    if (m == 8) {                                              // k2 = 128: Ys [256], Ms [16] (lane t, bits j)
+        c32 yh;
+        const int code = entry(tid, 0, yh);
+        Ys[(size_t)slice * 256 + tid] = yh;
+        __shared__ int codes[256];
+        codes[tid] = code;
+        __syncthreads();
+        if (tid < 16) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) v |= (uint32_t)codes[tid + 16 * jj] << (2 * jj);
+            Ms[slice * 16 + tid] = v;
+        }
+        return;
+    }
+    // the tile's 16 columns = four (set, wave) blocks of the table, 1024 entries each, written in storage order
+    const int set = m >> 1;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int o = tid + 256 * i, blk = o >> 10, e = o & 1023;           // block blk: columns 4 blk .. 4 blk + 3 of the tile
+        const int jp = e >> 7, lane = (e >> 1) & 63, j = 2 * jp + (e & 1);
+        const int g = lane >> 4, t = lane & 15, wv = 4 * (m & 1) + blk;
+        c32 yh;
+        (void)entry(t + 16 * j, 4 * blk + g, yh);
+        Yh[yh3_index(slice, set, j, wv, lane)] = yh;
+    }
+    {
+        const int blk = tid >> 6, lane = tid & 63, g = lane >> 4, t = lane & 15, wv = 4 * (m & 1) + blk;
         uint32_t v = 0;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) v |= (uint32_t)codes[k1 + 16 * jj] << (2 * jj);
-        if (k2 < 128) Mh[mh3_index(slice, set, wv, 16 * (c & 3) + k1)] = v;
-        else          Ms[slice * 16 + k1] = v;
+        for (int j = 0; j < 16; ++j) {
+            c32 yh;
+            v |= (uint32_t)entry(t + 16 * j, 4 * blk + g, yh) << (2 * j);
+        }
+        Mh[mh3_index(slice, set, wv, lane)] = v;
     }
 }
 
@@ -776,7 +824,7 @@ Slice256* slice256_create(int Bmax, hipError_t* err) {
 
 hipError_t slice256_prepare(Slice256* f, hipStream_t s, const float2* y, const uint8_t* mask_bank, const int32_t* mask_id, int B) {
     if (B > f->Bmax) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_sprepare, dim3(129, B), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank, mask_id,
+    hipLaunchKernelGGL(k_sprepare, dim3(9, B), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank, mask_id,
                        f->Yh, f->Mh, f->Ys, f->Ms);
     return hipGetLastError();
 }
