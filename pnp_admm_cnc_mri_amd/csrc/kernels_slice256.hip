@@ -21,6 +21,10 @@
 //     rows                      inverse FFT-256 -> x = |re|, |im| / N -> L1 / CNC z-update + dual update
 //                               -> v = z - w -> FFT-256          (S4:119-132; the last iteration also writes x)
 //
+// z and w live in HBM in the row transform's own thread order ("slice order", slice_layout.h: sl_state_index), so the
+// z- / w-update runs on the registers the inverse transform left and feeds the forward transform directly; api.hip converts
+// to and from the natural [256][256] order (k_state_order below) whenever anything else looks at the state.
+//
 // Row and column phases are wave-local (a 16-lane transform group never leaves its wave, each wave
 // has its own LDS region), so the 8 waves of the workgroup drift apart and cover each other's HBM
 // latency; only the two transpositions are workgroup barriers.  Same arithmetic cores as the fused
