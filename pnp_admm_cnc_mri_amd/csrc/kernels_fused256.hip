@@ -61,29 +61,69 @@ static inline ProxCoef to_coef(const ProxParams& p) {
 // ------------------------------------------------------------------------------------------
 // table preparation (once per uploaded problem)
 // ------------------------------------------------------------------------------------------
+// One block per (tile of 16 columns k2, slice pair); tile 8 = the column k2 = 128.  Each slice's y / mask tile and its mirror
+// image (rows -k1, columns -k2) go through LDS, so that global memory is read in 128-byte row segments and the table is
+// written in its own contiguous order (until round 3 a block held ONE column and read y with a 2 KiB stride: 2.5 GB fetched
+// for 0.4 GB of input at 512 slices).  Arithmetic = hermitian_entry (fused_layout.h).
+constexpr int FP_P = 17;
 __global__ __launch_bounds__(256) void k_fprepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
                                                   float4* Yh, unsigned long long* Mh, int B) {
-    __shared__ int nib[256];
-    const int tid = threadIdx.x, j = tid >> 4, t = tid & 15;
-    const int k2 = blockIdx.x, pair = blockIdx.y, k1 = t + 16 * j;
-    c32 yh[2] = {mk(0.f, 0.f), mk(0.f, 0.f)};
-    int code[2] = {0, 0};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int sl = 2 * pair + s;
+    __shared__ c32 yd[256 * FP_P], ym[256 * FP_P];
+    __shared__ uint8_t md[256 * FP_P], mm[256 * FP_P];
+    __shared__ uint8_t nib[256 * 16];                            // [k1][c]: code of slice a | code of slice b << 2
+    const int tid = threadIdx.x, m = blockIdx.x, pair = blockIdx.y;
+    const int ncol = (m == 8) ? 1 : 16;
+    c32 ya[16];                                                  // slice a's entries of this thread's 16 output positions
+    for (int e = tid; e < 256 * 16; e += 256) nib[e] = 0;
+#pragma unroll 1
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int sl = 2 * pair + sidx;
+        __syncthreads();
         if (sl < B) {
             const int mid = mask_id ? mask_id[sl] : 0;
-            hermitian_entry(y + (size_t)sl * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh[s], code[s]);
+            const c32* ys = y + (size_t)sl * 65536;
+            const uint8_t* ms = mask_bank + (size_t)mid * 65536;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
+                if (c < ncol) {
+                    const int k2 = 16 * m + c, k2m = (256 - k2) & 255;
+                    yd[r * FP_P + c] = ys[r * 256 + k2];
+                    md[r * FP_P + c] = ms[r * 256 + k2];
+                    ym[r * FP_P + c] = ys[r * 256 + k2m];
+                    mm[r * FP_P + c] = ms[r * 256 + k2m];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = tid + 256 * i;                         // storage order inside the tile: [wave 4][j 16][kl 16][tq 4]
+            const int tq = o & 3, kl = (o >> 2) & 15, j = (o >> 6) & 15, wv = o >> 10;
+            const int k1 = 4 * wv + tq + 16 * j, r2 = (256 - k1) & 255;
+            c32 yh = mk(0.f, 0.f);
+            int code = 0;
+            if (sl < B && kl < ncol) {
+                const int m1 = md[k1 * FP_P + kl] != 0, m2 = mm[r2 * FP_P + kl] != 0;
+                const c32 y1 = yd[k1 * FP_P + kl], y2 = ym[r2 * FP_P + kl];
+                // select, do not multiply: an unsampled y entry (possibly NaN/Inf in user data) must not reach the result
+                yh = mk(0.5f * ((m1 ? y1.x : 0.0f) + (m2 ? y2.x : 0.0f)), 0.5f * ((m1 ? y1.y : 0.0f) - (m2 ? y2.y : 0.0f)));
+                code = m1 + m2;
+            }
+            if (kl < ncol) nib[k1 * 16 + kl] |= (uint8_t)(code << (2 * sidx));      // one thread per (k1, kl): no race
+            if (sidx == 0) ya[i] = yh;
+            else if (kl < ncol) Yh[(size_t)pair * YH_PAIR + (size_t)m * 4096 + o] = make_float4(ya[i].x, ya[i].y, yh.x, yh.y);
         }
     }
-    Yh[yh_index(pair, k2, j, t)] = make_float4(yh[0].x, yh[0].y, yh[1].x, yh[1].y);
-    nib[tid] = code[0] | (code[1] << 2);
     __syncthreads();
-    if (tid < 16) {
-        unsigned long long v = 0;
+    {
+        const int tq = tid & 3, kl = (tid >> 2) & 15, wv = tid >> 6, t = 4 * wv + tq;
+        if (kl < ncol) {
+            unsigned long long v = 0;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) v |= (unsigned long long)nib[jj * 16 + tid] << (4 * jj);
-        Mh[mh_index(pair, k2, tid)] = v;
+            for (int jj = 0; jj < 16; ++jj) v |= (unsigned long long)nib[(t + 16 * jj) * 16 + kl] << (4 * jj);
+            Mh[(size_t)pair * MH_PAIR + (size_t)m * 256 + tid] = v;
+        }
     }
 }
 
@@ -350,7 +390,7 @@ hipError_t fused256_prepare(Fused256* f, hipStream_t s, const float2* y, const u
                             const int32_t* mask_id, int B) {
     if (B > f->Bmax) return hipErrorInvalidValue;
     const int np = (B + 1) / 2;
-    hipLaunchKernelGGL(k_fprepare, dim3(F_HALF, np), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank,
+    hipLaunchKernelGGL(k_fprepare, dim3(F_TILES, np), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank,
                        mask_id, f->Yh, f->Mh, B);
     return hipGetLastError();
 }
