@@ -299,11 +299,12 @@ static int set_masks(pnp_ctx* c, const uint8_t* mask_bank, const int32_t* mask_i
 }
 
 // One workgroup per slice, one workgroup per compute unit at a time: the batch runs in rounds of `cus` slices.
-// Measured on MI355X, ms per iteration, two-launch vs slice-resident (profiles/run_slice_sizes.sh, one box):
-//   B = 64: 0.0370 / 0.0369   80: 0.0410 / 0.0378   96: 0.0448 / 0.0382   128: 0.0544 / 0.0405   256: 0.0954 / 0.0565
-//   272: 0.1063 / 0.0904   320: 0.1224 / 0.0936   512: 0.1919 / 0.1075   640: 0.2506 / 0.1445
+// Measured on MI355X, ms per iteration, two-launch vs slice-resident (profiles/run_slice_sizes.sh, one box each):
+//   round 3 (profiles/slice_sizes_r03.txt):  B = 16: 0.0218 / 0.0289   32: 0.0253 / 0.0291   48: 0.0269 / 0.0302   56: 0.0290 / 0.0310
+//                                            64: 0.0340 / 0.0309   96: 0.0437 / 0.0319
+//   round 2:  B = 128: 0.0544 / 0.0405   256: 0.0954 / 0.0565   272: 0.1063 / 0.0904   320: 0.1224 / 0.0936   512: 0.1919 / 0.1075
 // A round costs the same full or not, and even a nearly empty second round (B = 272) beats the two-launch path:
-// the rule is simply "at least PNP_SLICE_MIN_B (64) slices".
+// the rule is simply "at least PNP_SLICE_MIN_B (64) slices" -- the crossover still sits between 56 and 64 with round 3's kernel.
 static bool slice_pays(pnp_ctx* c) {
     return c->slice_force || c->B >= c->slice_min_b;
 }
