@@ -433,6 +433,160 @@ static hipError_t launch_cols16_any(hipStream_t s, int W, bool pre, ColMid mid, 
     if (pre && !post && mid == MID_MASK_ADD)  return launch_cols16<true, MID_MASK_ADD, false>(s, W, a);
     return hipErrorInvalidValue;
 }
+// ------------------------------------------------------------------------------------------
+// the same for 512-row float arrays: 32 lanes x 16 points per column (fft16.h: structure A forward, t-layout -> k-layout;
+// structure B inverse, k-layout -> t-layout), 16 columns x 512 rows per 512-thread workgroup.
+//   t-layout: lane t, register j <-> row t + 32 j;   k-layout: lane 2 k2 + h, register q <-> row k2 + 16 q + 256 h
+// Column slot pitch 545 (= 1 mod 16: conflict-free transposing tile writes; >= 544 = the exchange region of 16 runs of 34).
+// ------------------------------------------------------------------------------------------
+constexpr int C32_P = 545;
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void col32_fwd(c32 (&a)[16], const c32* twl, c32* col, int t) {       // t-layout -> k-layout
+    const int k2 = t >> 1, h = t & 1;
+    fft512_a1<false>(a, twl + 17 * t);
+    stage_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) col[k * 34 + t] = a[k];
+    stage_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = col[k2 * 34 + 2 * i + h];
+    stage_sync();
+    fft512_a2<false>(a, h);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk<float>(lane_xor1(a[q].x), lane_xor1(a[q].y)), h);
+}
+__device__ __forceinline__ void col32_inv(c32 (&a)[16], const c32* twl, c32* col, int t) {       // k-layout -> t-layout
+    const int k2 = t >> 1, h = t & 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = bfly2(a[q], mk<float>(lane_xor1(a[q].x), lane_xor1(a[q].y)), h);
+    fft512_b1<true>(a, h);
+    stage_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) col[k2 * 34 + 2 * i + h] = a[i];
+    stage_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = col[k * 34 + t];
+    stage_sync();
+    fft512_b2<true>(a, twl + 17 * t);
+}
+
+template <bool PRE, int MID, bool POST>
+__global__ __launch_bounds__(512) void k_cols32(ColArgsT<float> p, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw32[];
+    c32* tile = reinterpret_cast<c32*>(smem_raw32);            // [16][C32_P]
+    c32* twl = tile + 16 * C32_P;                              // [32][17] = W512^(t k)
+    const int tid = threadIdx.x;
+    {
+        const float2 wv = g_tw512[((tid >> 4) * (tid & 15)) & 511];
+        twl[17 * (tid >> 4) + (tid & 15)] = mk<float>(wv.x, wv.y);
+    }
+    const int tiles = W / 16;
+    const int b = blockIdx.x / tiles;
+    const int k0 = (blockIdx.x % tiles) * 16;
+    const size_t sbase = (size_t)b * 512 * W;
+    const c32* in = reinterpret_cast<const c32*>(p.in);
+    c32* out = reinterpret_cast<c32*>(p.out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;
+        tile[c * C32_P + r] = in[sbase + (size_t)r * W + k0 + c];
+    }
+    __syncthreads();
+    const int c = tid >> 5, t = tid & 31, k2 = t >> 1, h = t & 1;
+    c32* col = tile + c * C32_P;
+    c32 a[16];
+    if (PRE) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = col[t + 32 * j];
+        col32_fwd(a, twl, col, t);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = col[k2 + 16 * q + 256 * h];
+    }
+    // a is in k-layout here
+    if (MID != MID_NONE) {
+        stage_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) col[k2 + 16 * q + 256 * h] = a[q];
+        __syncthreads();                                  // the pointwise pass walks the tile row-major (coalesced y / mask reads)
+        const int mid = p.mask_id ? p.mask_id[b] : 0;
+        const uint8_t* mask = p.mask_bank + (size_t)mid * 512 * W;
+        const c32* yb = reinterpret_cast<const c32*>(p.y) + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 512 * i, r = idx >> 4, cc = idx & 15;
+            const size_t g = (size_t)r * W + k0 + cc;
+            c32 X = tile[cc * C32_P + r];
+            const bool m = mask[g] != 0;
+            if (MID == MID_BLEND) {
+                if (m) { const c32 yv = yb[g]; X.x = fmaf(yv.x - X.x, p.c, X.x); X.y = fmaf(yv.y - X.y, p.c, X.y); }
+            } else if (MID == MID_MASK) {
+                if (!m) X = mk<float>(0.f, 0.f);
+            } else if (MID == MID_RESID) {
+                if (m) { const c32 yv = yb[g]; X.x -= yv.x; X.y -= yv.y; } else X = mk<float>(0.f, 0.f);
+            } else if (MID == MID_MASK_ADD) {
+                const c32 nv = yb[g];
+                X = m ? X + nv : nv;
+            }
+            tile[cc * C32_P + r] = X;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = col[k2 + 16 * q + 256 * h];
+    }
+    stage_sync();
+    if (POST) {
+        col32_inv(a, twl, col, t);
+        stage_sync();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) col[t + 32 * j] = a[j];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) col[k2 + 16 * q + 256 * h] = a[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, cc = idx & 15;
+        out[sbase + (size_t)r * W + k0 + cc] = tile[cc * C32_P + r];
+    }
+}
+
+template <bool PRE, int MID, bool POST>
+static hipError_t launch_cols32(hipStream_t s, int W, const ColArgsT<float>& a) {
+    const size_t lds = sizeof(c32) * (16 * C32_P + 32 * 17);
+    static bool attr_done[64] = {};         // >64 KiB dynamic LDS needs the opt-in once per kernel and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_cols32<PRE, MID, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((k_cols32<PRE, MID, POST>), dim3(a.B * (W / 16)), dim3(512), lds, s, a, W);
+    return hipGetLastError();
+}
+static hipError_t launch_cols32_any(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
+    if (pre && !post && mid == MID_NONE)      return launch_cols32<true, MID_NONE, false>(s, W, a);
+    if (!pre && post && mid == MID_NONE)      return launch_cols32<false, MID_NONE, true>(s, W, a);
+    if (pre && post && mid == MID_BLEND)      return launch_cols32<true, MID_BLEND, true>(s, W, a);
+    if (pre && !post && mid == MID_MASK)      return launch_cols32<true, MID_MASK, false>(s, W, a);
+    if (!pre && post && mid == MID_MASK)      return launch_cols32<false, MID_MASK, true>(s, W, a);
+    if (pre && post && mid == MID_RESID)      return launch_cols32<true, MID_RESID, true>(s, W, a);
+    if (pre && !post && mid == MID_MASK_ADD)  return launch_cols32<true, MID_MASK_ADD, false>(s, W, a);
+    return hipErrorInvalidValue;
+}
+template <typename R> static hipError_t cols32_or_stockham(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a);
+template <> hipError_t cols32_or_stockham<float>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
+    static const bool stockham = getenv("PNP_GENERIC_STOCKHAM") != nullptr;
+    return stockham ? launch_cols_n<512>(s, W, pre, mid, post, a) : launch_cols32_any(s, W, pre, mid, post, a);
+}
+template <> hipError_t cols32_or_stockham<double>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<double>& a) {
+    return launch_cols_n<512>(s, W, pre, mid, post, a);
+}
+
 template <typename R> static hipError_t cols16_or_stockham(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a);
 template <> hipError_t cols16_or_stockham<float>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
     static const bool stockham = getenv("PNP_GENERIC_STOCKHAM") != nullptr;      // developer knob: the four-stage LDS kernel (A/B runs)
@@ -446,7 +600,7 @@ template <typename R>
 hipError_t launch_cols(hipStream_t s, int H, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a) {
     if (W % 16) return hipErrorInvalidValue;
     if (H == 256) return cols16_or_stockham<R>(s, W, pre, mid, post, a);
-    if (H == 512) return launch_cols_n<512>(s, W, pre, mid, post, a);
+    if (H == 512) return cols32_or_stockham<R>(s, W, pre, mid, post, a);
     return hipErrorInvalidValue;
 }
 template hipError_t launch_cols<float>(hipStream_t, int, int, bool, ColMid, bool, const ColArgsT<float>&);
