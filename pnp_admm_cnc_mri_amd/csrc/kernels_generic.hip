@@ -473,7 +473,7 @@ __device__ __forceinline__ void col32_inv(c32 (&a)[16], const c32* twl, c32* col
 }
 
 template <bool PRE, int MID, bool POST>
-__global__ __launch_bounds__(512) void k_cols32(ColArgsT<float> p, int W) {
+__global__ __launch_bounds__(512, 4) void k_cols32(ColArgsT<float> p, int W) {      // 4 waves per SIMD = two workgroups per compute unit (74 KB of LDS each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw32[];
     c32* tile = reinterpret_cast<c32*>(smem_raw32);            // [16][C32_P]
     c32* twl = tile + 16 * C32_P;                              // [32][17] = W512^(t k)
