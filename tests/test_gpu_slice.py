@@ -252,3 +252,36 @@ def test_state_order_is_private_to_the_slice_path(P, golden_inputs, monkeypatch)
         xs = eng.x()
     for b in range(3):
         assert rel_l2(xs[b], O.admm_cnc(ys[b].astype(np.complex128), masks[mid[b]], 4)) <= 2e-6
+
+
+def test_driver_shaped_run_against_the_oracle_on_every_eighth_slice(P):
+    """BASELINE.json configs[1] exactly as bench.py runs it for the driver (512 synthetic slices, Q_Random30, S4:176 presets,
+    5 + 20 iterations as two calls, slice-resident kernel): 64 of the 512 reconstructions (every eighth slice, both rounds of
+    the launch, both parities) against the float64 NumPy oracle on the same measurements.
+    The bar is the north star's 1e-5.  The committed CNC presets make the map locally expansive, and a few slices amplify
+    float32 round-off far more than the rest (slice 227: 2e-6 after 15 iterations, 4-6e-5 after 25 -- in NumPy's own float32
+    run of the reference lines as in every kernel family here, profiles/check_slice_amplification.py): for those the bound is
+    twice the NumPy-float32 control on the same measurements, and they must stay rare."""
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    mask = S.reference_masks()['Q_Random30'].astype(np.uint8)
+    B = 512
+    img, noise = S.batch(0, B)
+    with P.Engine(256, 256, Bmax=B) as eng:
+        eng.synthesize(img, noise, mask[None], np.zeros(B, np.int32))
+        assert eng.path_name == 'slice'
+        y = eng.download_y()
+        eng.init_state()
+        eng.admm_cnc(5, 0.45, 0.5, 0.05, 64)
+        eng.admm_cnc(20, 0.45, 0.5, 0.05, 64)
+        x = eng.x()
+    assert np.isfinite(x).all()
+    beyond = []
+    for b in range(3, B, 8):
+        y128 = y[b].astype(np.complex128)
+        ref = O.admm_cnc(y128, mask, 25)
+        err = rel_l2(x[b], ref)
+        if err > 1e-5:
+            control = rel_l2(O.admm_cnc_f32(y128, mask, 25), ref)
+            assert err <= 2 * control, (b, err, control)
+            beyond.append(b)
+    assert len(beyond) <= 3, beyond                    # measured: 1 of 64 (slice 227)
