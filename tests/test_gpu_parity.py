@@ -273,14 +273,14 @@ def test_other_masks_golden(P, golden_inputs, golden_admm, mname, path):
 # ------------------------------------------------------------------------------------------------
 # batched synthetic workload (config 2 shape, small B) vs the oracle, mixed masks, odd B
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('fast', [0, 1])
+@pytest.mark.parametrize('path', PATHS)
 @pytest.mark.parametrize('B', [1, 5, 8])
-def test_batched_mixed_masks_vs_oracle(P, golden_inputs, B, fast):
+def test_batched_mixed_masks_vs_oracle(P, golden_inputs, B, path):
     masks = _masks(golden_inputs)
     imgs, ys, mid = _synthetic(B, masks)
-    with P.Engine(256, 256, Bmax=8) as eng:
-        eng.set_fast_path(fast)
+    with _engine_on(P, path, Bmax=8) as eng:
         eng.upload(ys, masks, mid)
+        eng.check()
         eng.init_state()
         eng.admm_l1(100, 0.1, 0.015)
         xl1 = eng.x()
