@@ -47,11 +47,12 @@ def cpu_baseline(masks, mask_id, budget_s=20.0, iters=100):
     from pnp_admm_cnc_mri_amd import synthetic as S
     t_used, n_slices = 0.0, 0
     # one untimed warm-up slice-solve of 5 iterations (imports, pocketfft plan cache)
-    y = O.synthesize(S.phantom(0), masks[mask_id[0]].astype(np.float64), S.kspace_noise(0))
+    n_avail = len(mask_id)
+    y = O.synthesize(S.phantom(0, H, W), masks[mask_id[0]].astype(np.float64), S.kspace_noise(0, H, W))
     O.admm_cnc(y, masks[mask_id[0]], 5, **PRESET)
-    while t_used < budget_s and n_slices < B_PER_GPU:
+    while t_used < budget_s and n_slices < n_avail:
         b = n_slices
-        y = O.synthesize(S.phantom(b), masks[mask_id[b]].astype(np.float64), S.kspace_noise(b))
+        y = O.synthesize(S.phantom(b, H, W), masks[mask_id[b]].astype(np.float64), S.kspace_noise(b, H, W))
         t0 = time.perf_counter()
         O.admm_cnc(y, masks[mask_id[b]], iters, **PRESET)
         t_used += time.perf_counter() - t0
@@ -65,14 +66,14 @@ def cpu_baseline(masks, mask_id, budget_s=20.0, iters=100):
 
 def _cpu_worker(args):
     """one worker of the all-cores baseline: whole 100-iteration solves of its own slices for `budget` s"""
-    first, stride, budget, iters = args
+    first, stride, budget, iters, size = args
     import numpy as _np
     from oracle import admm_oracle as O
     from pnp_admm_cnc_mri_amd import synthetic as S
-    mask = S.reference_masks()['Q_Random30'].astype(_np.uint8)
+    mask = (S.reference_masks()['Q_Random30'] if size == 256 else S.synthetic_mask('random', size, size)).astype(_np.uint8)
     t_used, n, b = 0.0, 0, first
     while t_used < budget:
-        y = O.synthesize(S.phantom(b), mask.astype(_np.float64), S.kspace_noise(b))
+        y = O.synthesize(S.phantom(b, size, size), mask.astype(_np.float64), S.kspace_noise(b, size, size))
         t0 = time.perf_counter()
         O.admm_cnc(y, mask, iters, **PRESET)
         t_used += time.perf_counter() - t0
@@ -89,7 +90,7 @@ def cpu_baseline_all_cores(budget_s=8.0, iters=100):
     os.environ.setdefault('OMP_NUM_THREADS', '1')
     with mp.get_context('spawn').Pool(cores) as pool:
         t0 = time.perf_counter()
-        res = pool.map(_cpu_worker, [(w, cores, budget_s, iters) for w in range(cores)])
+        res = pool.map(_cpu_worker, [(w, cores, budget_s, iters, H) for w in range(cores)])
         wall = time.perf_counter() - t0
     slice_it_s = sum(n * iters / t for n, t in res)          # sum of per-worker rates (start-up excluded)
     return {'value': slice_it_s / B_PER_GPU, 'unit': 'it/s (512-slice batches)', 'cores': cores, 'kind': 'port',
