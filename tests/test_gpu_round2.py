@@ -503,3 +503,16 @@ def test_bench_pnp_line_and_its_two_rank_launch():
     assert len(lines) == 1
     j2 = json.loads(lines[0])
     assert j2['n_gpus'] == 2 and j2['gather_ms'] is not None and j2['scaling'] == 'weak' and j2['x_finite']
+
+
+def test_bench_line_at_512_with_its_cpu_legs():
+    """`bench.py --size 512` (the shape of config 5) with the checker legs on: the metric string names the shape, the oracle
+    comparison and both CPU baselines run on 512 x 512 data (they once built 256 x 256 phantoms for a 512 x 512 mask)."""
+    env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '512', '--batch', '8', '--steps', '2', '--warmup', '1',
+                        '--cpu-budget', '0.5'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    j = json.loads(r.stdout.decode().strip())
+    assert '512x512' in j['metric'] and j['config']['path'] == 'fused' and j['f64'] is None
+    assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5 and j['parity']['iterations'] == 3
+    assert j['cpu_baseline']['value'] > 0 and j['cpu_baseline_all_cores'].get('value', 0) > 0
