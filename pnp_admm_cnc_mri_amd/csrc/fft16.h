@@ -75,14 +75,20 @@ __device__ __forceinline__ f2 rot2(f2 a) {     // 1.0 * a with the halves swappe
     return r;
 }
 // a * w (forward) / a * conj(w) (inverse):  t = (a.y w.y, a.y w.x | a.x w.y);  r = (a.x w.x -+ t.lo, a.x w.y + t.hi | a.y w.x - t.hi)
+// Both instructions sit in ONE asm statement: hipcc's hazard recognizer cannot see into inline asm and assumes that any asm
+// result may come from a dst_sel instruction (gfx940+ "dst_sel forwarding hazard"), so it put an s_nop between a product in
+// one asm statement and its use in the next -- 236 wasted issue slots per wave and iteration of the slice kernel.  A plain
+// VALU dependency needs no software wait state.
 #define PNP_PK_TMUL(CONSTRAINT)                                                                                                           \
-    f2 t, r;                                                                                                                              \
+    f2 r;                       /* the product of the first instruction lives in the result register: one asm output only */             \
     if (!INV) {                                                                                                                           \
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), CONSTRAINT(w));                                   \
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), CONSTRAINT(w), "v"(t));   \
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"                                                                     \
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"                                                  \
+            : "=&v"(r) : "v"(a), CONSTRAINT(w));                                                                                          \
     } else {                                                                                                                              \
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), CONSTRAINT(w));                                   \
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), CONSTRAINT(w), "v"(t));   \
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]\n\t"                                                                     \
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]"                                                  \
+            : "=&v"(r) : "v"(a), CONSTRAINT(w));                                                                                          \
     }                                                                                                                                     \
     return r;
 template <bool INV> __device__ __forceinline__ f2 tmul_v(f2 a, f2 w) { PNP_PK_TMUL("v") }      // w in registers (table twiddles)
