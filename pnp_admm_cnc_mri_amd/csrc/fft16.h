@@ -328,12 +328,18 @@ template <typename R> PNP_HD cxT<R> blend_one(cxT<R> V, cxT<R> yh, int code, R c
     const R A = fma_(-ch, (R)code, (R)1);
     return mk<R>(fma_(A, V.x, c * yh.x), fma_(A, V.y, c * yh.y));
 }
-// blend_one for a field that arrives DOUBLED (V2 = 2 V; the slice-resident kernel's transposition leaves the 1/2 of the
-// real-to-complex unpack out): A/2 = fma(-ch/2, code, 1/2) is the exact half of blend_one's A and (A/2)(2V) = A V exactly
-// (powers of two commute with rounding), so the result is blend_one(V, ...) bit for bit.  chh = ch / 2 = c / 4.
-template <typename R> PNP_HD cxT<R> blend_one_doubled(cxT<R> V2, cxT<R> yh, int code, R c, R chh) {
-    const R A = fma_(-chh, (R)code, (R)0.5);
-    return mk<R>(fma_(A, V2.x, c * yh.x), fma_(A, V2.y, c * yh.y));
+// blend_one with every coefficient scaled by a power of two s:  cs = c s, chs = ch s, os = s.  A_s = fma(-chs, code, os) is
+// exactly s A and fma(A_s, V, cs yh) exactly s blend_one(V, ...) (powers of two commute with rounding, underflow aside:
+// |values| < 2^-126 / s, i.e. 1e-33 for s = 2^-16 on a field of magnitude 1e4).  The slice-resident kernel uses it twice over:
+//   s = 1/N   -- the inverse transforms' normalisation rides on the blend, x = |.| needs no multiplication;
+//   s = 1/2N with the DOUBLED field V2 = 2 V its transposition leaves (the 1/2 of the real-to-complex unpack left out):
+//             (A_s / 2)(2 V) = A_s V exactly.
+template <typename R> PNP_HD cxT<R> blend_scaled_f(cxT<R> V, cxT<R> yh, R code, R cs, R chs, R os) {      // code already a float
+    const R A = fma_(-chs, code, os);
+    return mk<R>(fma_(A, V.x, cs * yh.x), fma_(A, V.y, cs * yh.y));
+}
+template <typename R> PNP_HD cxT<R> blend_scaled(cxT<R> V, cxT<R> yh, int code, R cs, R chs, R os) {
+    return blend_scaled_f(V, yh, (R)code, cs, chs, os);
 }
 template <typename R> PNP_HD cxT<R> repack_p(cxT<R> xa, cxT<R> xb) { return mk<R>(xa.x - xb.y, xa.y + xb.x); }
 template <typename R> PNP_HD cxT<R> repack_q(cxT<R> xa, cxT<R> xb) { return mk<R>(xa.x + xb.y, xb.x - xa.y); }

@@ -108,6 +108,7 @@ __device__ __forceinline__ void prio_set(int wv, int set) {
 #if SLICE_PRIOSWAP
     const bool older_high = (SLICE_PRIOMASK >> set) & 1;              // compile-time per set
     if (set == 0 || (((SLICE_PRIOMASK >> set) ^ (SLICE_PRIOMASK >> (set - 1))) & 1)) {      // only where the pattern changes
+        asm volatile("" : "+s"(wv));          // compared afresh at every site (s_cmp): a boolean kept across the loop cost a register and a spill
         if ((wv < 4) == older_high) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
 #endif
@@ -183,6 +184,21 @@ __device__ __forceinline__ float sub_partner(float a, float b) {          // a -
 __device__ __forceinline__ float add_partner(float a, float b) {          // a + dpp(b)
     float r;
     asm("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+
+// |a| + w as one instruction.  (Written in C the compiler shares the |.| with the x store of the final iteration, hoists
+// 128 v_and in front of that branch and adds packed: three instructions per register pair instead of two.)
+__device__ __forceinline__ float abs_plus(float a, float w) {
+    float r;
+    asm("v_add_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+
+// a - b as ONE packed instruction (hipcc turned the v = z - w in front of the forward transform into four v_sub_f32 per access)
+__device__ __forceinline__ f2 sub2(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -269,8 +285,7 @@ __device__ __forceinline__ f2 splat(float v) { return k2(v, v); }
 // z / w updates of TWO pixels -- the same column of image rows 2r and 2r + 1 (prox_l1_pt / prox_cnc_pt of fft16.h, same
 // operation order per pixel)
 template <int PROX>
-__device__ __forceinline__ void prox_pair(f2 x, f2& z, f2& w, const ProxCoef& pc) {
-    const f2 u = x + w;
+__device__ __forceinline__ void prox_pair(f2 u, f2& z, f2& w, const ProxCoef& pc) {      // u = x + w
     if (PROX == 2) {
         const f2 cz = clamp2(z, pc.ib);                                          // z - soft(z, 1/b)
         const f2 t = fma2(splat(pc.c1), z, fma2(splat(pc.c2), u, splat(pc.c3) * cz));
@@ -288,21 +303,19 @@ __device__ __forceinline__ void prox_pair(f2 x, f2& z, f2& w, const ProxCoef& pc
 // a second instance for the final iteration spills 350-490 bytes per lane), at the price of one unused forward
 // transform per launch.
 template <bool HAS_INV, int PROX, bool HAS_FWD>
-__device__ __forceinline__ void pointwise_q(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last,
+__device__ __forceinline__ void pointwise_q(const SliceBufs& b, const ProxCoef& pc, int u_first, bool last,
                                             c32& a0, c32& a1, const float (&z_)[4], const float (&w_)[4], int vs) {
     f2 z[2] = {k2(z_[0], z_[1]), k2(z_[2], z_[3])}, w[2] = {k2(w_[0], w_[1]), k2(w_[2], w_[3])};
-    f2 x[2] = {splat(0.f), splat(0.f)};
-    if (HAS_INV) {
-        x[0] = k2(fabsf(a0.x) * scale, fabsf(a0.y) * scale);
-        x[1] = k2(fabsf(a1.x) * scale, fabsf(a1.y) * scale);
-    }
+    // u = x + w with x = |re|, |im| (the 1/N of the inverse transform is already in the field, col_phase): two v_add_f32 with
+    // the |.| source modifier per register pair -- a packed add has no such modifier and would cost two v_and on top
+#define SL_X_PLUS(a_, w_) (HAS_INV ? k2(abs_plus((a_).x, (w_).x), abs_plus((a_).y, (w_).y)) : (w_))
 #define SL_ST4(buf, v) { const float q_[4] = {v[0].x, v[0].y, v[1].x, v[1].y}; st4(buf, vs, 0, q_); }
     if (PROX == 3) {                                   // ADMM_L1 single-state form: the w buffer carries u = x + w_old
         f2 u[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             if (!u_first) w[jj] = w[jj] - (w[jj] - clamp2(w[jj], pc.thr));
-            u[jj] = x[jj] + w[jj];
+            u[jj] = SL_X_PLUS(jj ? a1 : a0, w[jj]);
             z[jj] = u[jj] - clamp2(u[jj], pc.thr);
             w[jj] = u[jj] - z[jj];
         }
@@ -315,13 +328,14 @@ __device__ __forceinline__ void pointwise_q(const SliceBufs& b, const ProxCoef& 
     }
     if (PROX == 1 || PROX == 2) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) prox_pair<PROX>(x[jj], z[jj], w[jj], pc);
+        for (int jj = 0; jj < 2; ++jj) prox_pair<PROX>(SL_X_PLUS(jj ? a1 : a0, w[jj]), z[jj], w[jj], pc);
         SL_ST4(b.z, z);
         SL_ST4(b.w, w);
     }
 #undef SL_ST4
+#undef SL_X_PLUS
     if (HAS_FWD) {
-        const f2 v0 = z[0] - w[0], v1 = z[1] - w[1];
+        const f2 v0 = sub2(z[0], w[0]), v1 = sub2(z[1], w[1]);
         a0 = from2(v0);
         a1 = from2(v1);
     }
@@ -330,11 +344,11 @@ __device__ __forceinline__ void pointwise_q(const SliceBufs& b, const ProxCoef& 
 // x of the last iteration leaves in NATURAL order (it is the caller's result): the set's x = |re|, |im| / N goes through
 // the wave's four exchange regions once -- region g holds row pair g of the set as 256 complex (row 2r, row 2r + 1) -- and
 // every lane stores 4 consecutive pixels of both rows of each pair.  Once per launch.
-__device__ __forceinline__ void store_x_natural(const SliceBufs& b, float scale, const c32 (&a)[16], c32* wreg, int set, int wv, int lane) {
+__device__ __forceinline__ void store_x_natural(const SliceBufs& b, const c32 (&a)[16], c32* wreg, int set, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) region[t + 16 * j] = mk<float>(fabsf(a[j].x) * scale, fabsf(a[j].y) * scale);
+    for (int j = 0; j < 16; ++j) region[t + 16 * j] = mk<float>(fabsf(a[j].x), fabsf(a[j].y));
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -357,7 +371,7 @@ __device__ __forceinline__ void row_phase_prefetch(const SliceBufs& b, RowLoads&
     issue_row_loads<PROX, HAS_INV, 0, row_pf<PROX>()>(b, L, row_set_offset(0, wv), 2048 * (lane >> 4) + 16 * (lane & 15));
 }
 template <bool HAS_INV, int PROX, bool HAS_FWD, bool PRELOADED = false>
-__device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, float scale, int u_first, bool last, c32 (&F)[SL_SETS][16],
+__device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc, int u_first, bool last, c32 (&F)[SL_SETS][16],
                                           c32* wreg, const c32* twl, int wv, int lane, RowLoads* pre = nullptr) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
@@ -377,14 +391,14 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
             group_fft256<true>(a, twl, region, t);
 #endif
         }
-        if (HAS_INV && last) store_x_natural(b, scale, a, wreg, set, wv, lane);
+        if (HAS_INV && last) store_x_natural(b, a, wreg, set, wv, lane);
         const int vs = voff + soff;
         // rolling fetch: access q + PF goes out when access q is consumed (PF accesses = 8 PF registers in flight; all 8 at
         // once, on top of the 128 data registers, made hipcc spill)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q + PF < 8) issue_row_loads<PROX, HAS_INV, 0, 1>(b, L, soff, voff, q + PF);
-            pointwise_q<HAS_INV, PROX, HAS_FWD>(b, pc, scale, u_first, last, a[2 * q], a[2 * q + 1], L.z[q], L.w[q], vs + ROW_QSTRIDE * q);
+            pointwise_q<HAS_INV, PROX, HAS_FWD>(b, pc, u_first, last, a[2 * q], a[2 * q + 1], L.z[q], L.w[q], vs + ROW_QSTRIDE * q);
 #ifdef SLICE_PW_SCHED
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -454,6 +468,33 @@ __device__ __forceinline__ void t_load_rows(c32 (&F)[16], const c32* rp, int t) 
 //   the column phase works on the doubled field and takes the 1/2 back in its blend coefficient (exactly: a power of two)
 // The 16 reads of a column go out in two groups of 8 (until round 3 every read was waited for on its own: 64 serial LDS
 // round trips per wave and iteration).
+// One column-form set's 16 values from the buffer.  MAYBE_PACKED: this wave owns the packed column c = 0 (wave 0, first
+// set of pass 0, lanes 0..15 -- `packed` says which lanes); every other (wave, set) runs the plain two-instruction unpack.
+// Buffer rows 64.. (j >= 8) lie beyond the 16-bit offset of a DS instruction: a second base keeps the offsets immediates.
+template <bool MAYBE_PACKED>
+__device__ __forceinline__ void t1_read_col(c32 (&Gs)[16], const c32* buf, int off, int odd, bool packed) {
+    int off_hi = off + 64 * SL_P;
+    asm volatile("" : "+v"(off_hi));                // an index, not a pointer: the address space stays visible to the compiler
+    const c32 *col = buf + off, *col_hi = buf + off_hi;
+#pragma unroll
+    for (int jb = 0; jb < 16; jb += 8) {
+        c32 own[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) own[k] = jb ? col_hi[8 * k * SL_P] : col[8 * k * SL_P];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // TWICE the unpacked value: the 1/2 is folded into the blend coefficients (blend_scaled, exact)
+            c32 v = mk<float>(add_partner(own[k].x, own[k].y), sub_partner(own[k].y, own[k].x));
+            if (MAYBE_PACKED) {                     // the packed column c = 0 takes the raw values: (C[0], C[128]) -> re / im parts
+                const float oy = dpp_lane_xor1(own[k].y);
+                const c32 raw = mk<float>(odd ? oy : own[k].x, odd ? own[k].x : oy);
+                v = packed ? raw : v;
+            }
+            Gs[jb + k] = v;
+            pin(Gs[jb + k]);                        // unpack as the values arrive: raw values must not pile up across the barrier
+        }
+    }
+}
 template <int P>
 __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL_SETS][16], c32* buf, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
@@ -463,52 +504,42 @@ __device__ __forceinline__ void t1_pass(const c32 (&F)[SL_SETS][16], c32 (&G)[SL
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                       // the two column-form sets of this pass: 2P and 2P + 1
         const int cc = 32 * h + 4 * wv + g, odd = t & 1;
-        const bool packed = (P == 0 && h == 0 && cc == 0);
-        const c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
-#pragma unroll
-        for (int jb = 0; jb < 16; jb += 8) {
-            c32 own[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) own[k] = col[8 * (jb + k) * SL_P];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // TWICE the unpacked value: the 1/2 is folded into the blend coefficient (blend_one_doubled, exact)
-                c32 v = mk<float>(add_partner(own[k].x, own[k].y), sub_partner(own[k].y, own[k].x));
-                if (P == 0 && h == 0) {                 // the packed column c = 0 takes the raw values: (C[0], C[128]) -> re / im parts
-                    const float oy = dpp_lane_xor1(own[k].y);
-                    const c32 raw = mk<float>(odd ? oy : own[k].x, odd ? own[k].x : oy);
-                    v = packed ? raw : v;
-                }
-                G[2 * P + h][jb + k] = v;
-                pin(G[2 * P + h][jb + k]);              // unpack as the values arrive: raw values must not pile up across the barrier
-            }
-        }
+        const int off = (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
+        if (P == 0 && h == 0 && wv == 0) t1_read_col<true>(G[2 * P + h], buf, off, odd, cc == 0);      // wv is wave-uniform: a scalar branch
+        else t1_read_col<false>(G[2 * P + h], buf, off, odd, false);
     }
     __syncthreads();
 }
 
+template <bool MAYBE_PACKED>
+__device__ __forceinline__ void t2_write_col(const c32 (&Gs)[16], c32* buf, int off, int odd, bool packed) {
+    int off_hi = off + 64 * SL_P;
+    asm volatile("" : "+v"(off_hi));
+    c32 *col = buf + off, *col_hi = buf + off_hi;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        // the lane pair (even, odd) holds (ue, uo) = column values of image rows 2r, 2r + 1; the even lane writes
+        // repack_p(ue, uo) = ue + i uo to the direct slot, the odd lane repack_q(ue, uo) = conj ue + i conj uo to the mirror
+        // slot -- with its halves swapped, which makes both lanes' values ( own.x - partner's own.y,  own.y + partner's own.x )
+        const c32 own = Gs[j];
+        c32 v = mk<float>(sub_partner(own.x, own.y), add_partner(own.y, own.x));
+        if (MAYBE_PACKED) {                         // packed column: (ue.x, uo.x) direct, (ue.y, uo.y) mirror (stored swapped)
+            const c32 other = dpp_lane_xor1(own);
+            const c32 raw = mk<float>(odd ? own.y : own.x, odd ? other.y : other.x);
+            v = packed ? raw : v;
+        }
+        if (j < 8) col[8 * j * SL_P] = v; else col_hi[8 * (j - 8) * SL_P] = v;
+    }
+}
 template <int P>
 __device__ __forceinline__ void t2_pass(const c32 (&G)[SL_SETS][16], c32 (&F)[SL_SETS][16], c32* buf, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int cc = 32 * h + 4 * wv + g, odd = t & 1;
-        const bool packed = (P == 0 && h == 0 && cc == 0);
-        c32* col = buf + (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            // the lane pair (even, odd) holds (ue, uo) = column values of image rows 2r, 2r + 1; the even lane writes
-            // repack_p(ue, uo) = ue + i uo to the direct slot, the odd lane repack_q(ue, uo) = conj ue + i conj uo to the mirror
-            // slot -- with its halves swapped, which makes both lanes' values ( own.x - partner's own.y,  own.y + partner's own.x )
-            const c32 own = G[2 * P + h][j];
-            c32 v = mk<float>(sub_partner(own.x, own.y), add_partner(own.y, own.x));
-            if (P == 0 && h == 0) {                     // packed column: (ue.x, uo.x) direct, (ue.y, uo.y) mirror (stored swapped)
-                const c32 other = dpp_lane_xor1(own);
-                const c32 raw = mk<float>(odd ? own.y : own.x, odd ? other.y : other.x);
-                v = packed ? raw : v;
-            }
-            col[8 * j * SL_P] = v;
-        }
+        const int off = (t >> 1) * SL_P + cc + (odd ? SL_M : 0);
+        if (P == 0 && h == 0 && wv == 0) t2_write_col<true>(G[2 * P + h], buf, off, odd, cc == 0);     // wv is wave-uniform: a scalar branch
+        else t2_write_col<false>(G[2 * P + h], buf, off, odd, false);
     }
     __syncthreads();
 #pragma unroll
@@ -534,10 +565,35 @@ __device__ __forceinline__ void issue_col_loads(const SliceBufs& b, ColLoads& Y,
     }
 }
 
-__device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G)[SL_SETS][16], c32* wreg, c32* ysl, const c32* twl, int wv, int lane) {
+// blend_scaled (fft16.h) over a lane's 16 values, the same arithmetic in fewer instructions: the code word holds 2 bits per j at bit
+// 2 j = byte j / 4, bits 2 (j % 4), so four masked copies put every code into a byte of its own and v_cvt_f32_ubyteN converts it
+// straight from there (hipcc: a v_bfe_u32 and a v_cvt per value), and the coefficients A = fma(-chs, code, os) of a pair (j, j + 1)
+// come out of one packed fma, each half broadcast by the blend's op_sel.  63 instructions per set instead of 78.
+__device__ __forceinline__ float code_byte(unsigned m, int byte) {
+    float r;
+    if (byte == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(m));
+    else if (byte == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(m));
+    else if (byte == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(m));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(m));
+    return r;
+}
+__device__ __forceinline__ void blend_set(c32 (&a)[16], const c32 (&yh)[16], unsigned code, float cs, float chs, float os) {
+    const unsigned m[4] = {code & 0x03030303u, (code >> 2) & 0x03030303u, (code >> 4) & 0x03030303u, (code >> 6) & 0x03030303u};
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const f2 cf = k2(code_byte(m[j & 3], j >> 2), code_byte(m[(j & 3) + 1], j >> 2));
+        const f2 A2 = fma2(splat(-chs), cf, splat(os));
+        a[j] = from2(fma2(A2.xx, to2(a[j]), splat(cs) * to2(yh[j])));
+        a[j + 1] = from2(fma2(A2.yy, to2(a[j + 1]), splat(cs) * to2(yh[j + 1])));
+    }
+}
+
+__device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, float scale, c32 (&G)[SL_SETS][16], c32* wreg, c32* ysl, const c32* twl, int wv, int lane) {
     const int g = lane >> 4, t = lane & 15;
     c32* region = wreg + g * REGION;
-    const float ch = 0.5f * cdc;
+    // the blend also applies the inverse transforms' 1/N (scale, a power of two): every coefficient of blend_scaled carries it,
+    // the blended field is exactly scale x blend_one's, and the inverse transforms deliver x without a multiplication per pixel
+    const float cs = cdc * scale, chs = 0.5f * cdc * scale;
     ColLoads Y;
     issue_col_loads(b, Y, 0, wv, lane);
     if (wv == 0) {
@@ -554,22 +610,27 @@ __device__ __forceinline__ void col_phase(const SliceBufs& b, float cdc, c32 (&G
         prio_set(wv, set);
         group_fft256<false>(a, twl, region, t);                   // a[j] = spectrum at k1 = t + 16 j, k2 = c
         if (set == 0 && wv == 0 && g == 0) {
-            // packed column: a = A + i B, A / B = spectra of the real columns k2 = 0 / 128; split with the mirror k1 -> -k1
+            // packed column: a = A + i B, A / B = spectra of the real columns k2 = 0 / 128; split with the mirror k1 -> -k1.
+            // The region holds the column plus a wrap-around copy of its first 16 values, so that the mirror of
+            // k1 = t + 16 j is region[256 - k1] = (region + 16 - t)[16 (15 - j)] for every (t, j): one address, immediates.
 #pragma unroll
             for (int j = 0; j < 16; ++j) region[t + 16 * j] = a[j];
+            region[256 + t] = a[0];
             wave_sync();
             const uint32_t code_b = reinterpret_cast<const uint32_t*>(ysl + 256)[t];
+            const c32* mirror = region + (16 - t);
+            const unsigned ma[4] = {Y.code & 0x03030303u, (Y.code >> 2) & 0x03030303u, (Y.code >> 4) & 0x03030303u, (Y.code >> 6) & 0x03030303u};
+            const unsigned mb[4] = {code_b & 0x03030303u, (code_b >> 2) & 0x03030303u, (code_b >> 4) & 0x03030303u, (code_b >> 6) & 0x03030303u};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const c32 gm = region[(256 - (t + 16 * j)) & 255];
-                const c32 A = blend_one(unpack_a(a[j], gm), Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, ch);
-                const c32 Bv = blend_one(unpack_b(a[j], gm), ysl[t + 16 * j], (int)((code_b >> (2 * j)) & 3u), cdc, ch);
+                const c32 gm = mirror[16 * (15 - j)];
+                const c32 A = blend_scaled_f(unpack_a(a[j], gm), Y.yh[j], code_byte(ma[j & 3], j >> 2), cs, chs, scale);
+                const c32 Bv = blend_scaled_f(unpack_b(a[j], gm), ysl[t + 16 * j], code_byte(mb[j & 3], j >> 2), cs, chs, scale);
                 a[j] = repack_p(A, Bv);
             }
             wave_sync();
         } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = blend_one_doubled(a[j], Y.yh[j], (int)((Y.code >> (2 * j)) & 3u), cdc, 0.5f * ch);
+            blend_set(a, Y.yh, Y.code, cs, 0.5f * chs, 0.5f * scale);        // doubled field: half the coefficients
         }
         if (set + 1 < SL_SETS) issue_col_loads(b, Y, set + 1, wv, lane);
         group_fft256<true>(a, twl, region, t);                    // column c of the blended field, unnormalised
@@ -606,7 +667,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
 #define SL_STAMP()
 #endif
         SL_STAMP();
-        row_phase<false, 0, true>(b, p.prox, p.scale, 1, false, F, wreg, twl, wv, opaque(lane));
+        row_phase<false, 0, true>(b, p.prox, 1, false, F, wreg, twl, wv, opaque(lane));
         SL_STAMP();
         for (int it = 0; it < p.iters; ++it) {
             c32 G[SL_SETS][16];
@@ -619,7 +680,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
 #else
             SL_STAMP();
 #endif
-            col_phase(b, p.c, G, wreg, lds + SL_YS, twl, wv, opaque(lane));
+            col_phase(b, p.c, p.scale, G, wreg, lds + SL_YS, twl, wv, opaque(lane));
             SL_STAMP();
             __syncthreads();
             SL_STAMP();
@@ -632,9 +693,9 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
             SL_STAMP();
             const int u_first = (it == 0);
 #if SLICE_EARLY
-            row_phase<true, PROX, true, true>(b, p.prox, p.scale, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane), &L0);
+            row_phase<true, PROX, true, true>(b, p.prox, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane), &L0);
 #else
-            row_phase<true, PROX, true>(b, p.prox, p.scale, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane));
+            row_phase<true, PROX, true>(b, p.prox, u_first, it + 1 == p.iters, F, wreg, twl, wv, opaque(lane));
 #endif
             SL_STAMP();
         }

@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
         if (written != 128 * 128) return 7;
         // the kernel's lane-level form (t1_pass): the even lane of a pair reads C[c], the odd lane C[-c] with its halves swapped;
         // the partner's halves arrive by DPP inside one add and one subtract, the same for both parities.  The result is
-        // TWICE the unpacked value (the 1/2 sits in the blend coefficient, blend_one_doubled)
+        // TWICE the unpacked value (the 1/2 sits in the blend coefficients, blend_scaled)
         for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 2 * p; set < 2 * p + 2; ++set) {
             const int c = sl_unit(set, wv, lane), t = lane & 15, cc = c & 63, odd = t & 1;
             for (int j = 0; j < 16; ++j) {
@@ -139,7 +139,9 @@ int main(int argc, char** argv) {
     }
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) for (int j = 0; j < 16; ++j) F[wv][lane][set][j] = G[wv][lane][set][j];
     // ---- columns: transform, blend, inverse transform ------------------------------------------
-    const R ch = 0.5f * cdc;
+    // the kernel's blend carries the inverse transforms' 1/N (blend_scaled, fft16.h): checked here, value by value, to be
+    // exactly scale x blend_one, so that x = |.| below needs no multiplication
+    const R ch = 0.5f * cdc, scale = 1.0f / 65536.0f, cs = cdc * scale, chs = ch * scale;
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < SL_SETS; ++set) {
         group_fft(wv, g, set, false);
         const int c = sl_unit(set, wv, 16 * g);
@@ -149,18 +151,21 @@ int main(int argc, char** argv) {
             for (int t = 0; t < 16; ++t) for (int j = 0; j < 16; ++j) {
                 const int k1 = t + 16 * j, lane = 16 * g + t;
                 const C gk = Gk[k1], gm = Gk[(256 - k1) & 255];
-                const C A = blend_one(unpack_a(gk, gm), Yh[yh3_index(0, set, j, wv, lane)], (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, ch);
-                const C Bv = blend_one(unpack_b(gk, gm), Ys[k1], (int)((Ms[t] >> (2 * j)) & 3u), cdc, ch);
+                const C A1 = blend_one(unpack_a(gk, gm), Yh[yh3_index(0, set, j, wv, lane)], (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, ch);
+                const C B1 = blend_one(unpack_b(gk, gm), Ys[k1], (int)((Ms[t] >> (2 * j)) & 3u), cdc, ch);
+                const C A = blend_scaled(unpack_a(gk, gm), Yh[yh3_index(0, set, j, wv, lane)], (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cs, chs, scale);
+                const C Bv = blend_scaled(unpack_b(gk, gm), Ys[k1], (int)((Ms[t] >> (2 * j)) & 3u), cs, chs, scale);
+                if (A.x != scale * A1.x || A.y != scale * A1.y || Bv.x != scale * B1.x || Bv.y != scale * B1.y) return 18;
                 F[wv][lane][set][j] = repack_p(A, Bv);
             }
         } else {
             for (int t = 0; t < 16; ++t) for (int j = 0; j < 16; ++j) {
                 const int lane = 16 * g + t;
                 const C v2 = F[wv][lane][set][j];                                          // the doubled field
-                const C got = blend_one_doubled(v2, Yh[yh3_index(0, set, j, wv, lane)], (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, (R)0.5 * ch);
+                const C got = blend_scaled(v2, Yh[yh3_index(0, set, j, wv, lane)], (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cs, (R)0.5 * chs, (R)0.5 * scale);
                 const C ref = blend_one(mk<R>((R)0.5 * v2.x, (R)0.5 * v2.y), Yh[yh3_index(0, set, j, wv, lane)],
                                         (int)((Mh[mh3_index(0, set, wv, lane)] >> (2 * j)) & 3u), cdc, ch);
-                if (got.x != ref.x || got.y != ref.y) return 17;                          // folding the 1/2 into the coefficient is exact
+                if (got.x != scale * ref.x || got.y != scale * ref.y) return 17;          // folding 1/2 and 1/N into the coefficients is exact
                 F[wv][lane][set][j] = got;
             }
         }
@@ -196,16 +201,15 @@ int main(int argc, char** argv) {
         }
     }
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) for (int j = 0; j < 16; ++j) F[wv][lane][set][j] = G[wv][lane][set][j];
-    // ---- rows (last): inverse transform, x = |re|, |im| / 65536, prox --------------------------------
+    // ---- rows (last): inverse transform, x = |re|, |im| (the 1/65536 came with the blend), prox -------
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int g = 0; g < 4; ++g) for (int set = 0; set < SL_SETS; ++set) group_fft(wv, g, set, true);
-    const R scale = 1.0f / 65536.0f;
     for (int wv = 0; wv < SL_WAVES; ++wv) for (int lane = 0; lane < 64; ++lane) for (int set = 0; set < SL_SETS; ++set) {
         const int r = sl_unit(set, wv, lane), t = lane & 15;
         for (int j = 0; j < 16; ++j) {
             const int n = t + 16 * j;
             const C o = F[wv][lane][set][j];
             const size_t ia = sl_state_index(2 * r, n), ib = sl_state_index(2 * r + 1, n);
-            const R xa = std::fabs(o.x) * scale, xb = std::fabs(o.y) * scale;
+            const R xa = std::fabs(o.x), xb = std::fabs(o.y);
             x[(2 * r) * 256 + n] = xa; x[(2 * r + 1) * 256 + n] = xb;                   // x leaves in natural order
             if (cnc) { prox_cnc_pt(xa, zs[ia], ws[ia], pc); prox_cnc_pt(xb, zs[ib], ws[ib], pc); }
             else     { prox_l1_pt(xa, zs[ia], ws[ia], pc);  prox_l1_pt(xb, zs[ib], ws[ib], pc); }
