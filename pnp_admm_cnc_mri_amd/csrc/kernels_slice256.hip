@@ -134,9 +134,6 @@ __device__ __forceinline__ bufrsrc make_rsrc(const void* base, unsigned bytes) {
 // z / w that THIS workgroup stored one iteration earlier inside the same launch (defensive: the vector L1 is
 // not refreshed by stores; costs nothing measurable on 16-byte streaming loads).
 __device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]) {
-#ifdef SLICE_ABLATE_ROWMEM          // timing experiment only (results are wrong)
-    v[0] = v[1] = v[2] = v[3] = 0.25f; return;
-#endif
     const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
     v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
 }
@@ -148,10 +145,6 @@ __device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]
 __device__ __forceinline__ void st4(bufrsrc r, int voff, int soff, const float (&v)[4]) {
     u32x4 q;
     q.x = __float_as_uint(v[0]); q.y = __float_as_uint(v[1]); q.z = __float_as_uint(v[2]); q.w = __float_as_uint(v[3]);
-#ifdef SLICE_ABLATE_ROWSTORE        // timing experiment only (results are wrong)
-    if (q.x == 0x7fc12345u) __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, 0);
-    return;
-#endif
     __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + soff, 0, SLICE_ST_AUX);
 }
 __device__ __forceinline__ c32 ldc(bufrsrc r, int voff, int soff) {
@@ -387,9 +380,7 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
         prio_set(wv, set);
         const int soff = row_set_offset(set, wv);
         if (HAS_INV) {
-#ifndef SLICE_ABLATE_ROWFFT
             group_fft256<true>(a, twl, region, t);
-#endif
         }
         if (HAS_INV && last) store_x_natural(b, a, wreg, set, wv, lane);
         const int vs = voff + soff;
@@ -399,15 +390,10 @@ __device__ __forceinline__ void row_phase(const SliceBufs& b, const ProxCoef& pc
         for (int q = 0; q < 8; ++q) {
             if (q + PF < 8) issue_row_loads<PROX, HAS_INV, 0, 1>(b, L, soff, voff, q + PF);
             pointwise_q<HAS_INV, PROX, HAS_FWD>(b, pc, u_first, last, a[2 * q], a[2 * q + 1], L.z[q], L.w[q], vs + ROW_QSTRIDE * q);
-#ifdef SLICE_PW_SCHED
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         if (set + 1 < SL_SETS) issue_row_loads<PROX, HAS_INV, 0, PF>(b, L, row_set_offset(set + 1, wv), voff);
         if (HAS_FWD) {
-#ifndef SLICE_ABLATE_ROWFFT
             group_fft256<false>(a, twl, region, t);
-#endif
         }
     }
 }
