@@ -16,7 +16,14 @@ PNP_GENERIC_STOCKHAM=1 python3 bench.py --generic --no-cpu-baseline > $O/generic
 python3 bench.py --gpus 2 --rehearse-gloo --steps 20 --warmup 5 > $O/gpus2_rehearsal.json 2>/dev/null
 PNP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/rccl_one_rank.json 2>/dev/null
 python3 bench.py --batch 1024 --no-cpu-baseline > $O/batch1024_100.json 2>/dev/null
-for f in $O/*.json; do echo "$(basename $f): $(grep -o '"value": [0-9.]*' $f | head -1) $(grep -o '"ms_per_step": [0-9.]*' $f | head -1) $(grep -o '"frac_measured": [0-9.a-z]*' $f | head -1)"; done
+python3 - $O <<'PY'
+import glob, json, os, sys
+for f in sorted(glob.glob(sys.argv[1] + '/*.json')):
+    for l in open(f):
+        if l.startswith('{'):
+            d = json.loads(l); r = d.get('roofline', {})
+            print('%s: value %.1f  ms_per_step %.5f  frac_measured %s' % (os.path.basename(f), d['value'], d['ms_per_step'], r.get('frac_measured')))
+PY
 python3 bench_pnp.py --model ffdnet_gray --batch 512 --steps 6 --warmup 2 > $O/pnp_ffdnet.json 2>/dev/null; tail -1 $O/pnp_ffdnet.json | cut -c1-300
 python3 bench_pnp.py --model drunet_gray --batch 512 --steps 2 --warmup 1 > $O/pnp_drunet.json 2>/dev/null; tail -1 $O/pnp_drunet.json | cut -c1-300
 python3 bench_pnp.py --model drunet_gray --size 512 --batch 64 --cnn-batch 16 --steps 2 --warmup 1 > $O/pnp_drunet512.json 2>/dev/null; tail -1 $O/pnp_drunet512.json | cut -c1-300
