@@ -113,11 +113,12 @@ static ProxParams make_prox_cnc(double alpha, double lambda1, double reo, double
 static float dc_coeff(double reo) { return (float)(1.0 / (1.0 + 1.0 / 2.0 / reo)); }
 
 // The slice-resident loops keep z / w in their own order; everything else (the other kernel families, pnp_get_state /
-// pnp_set_state, pnp_init_state) sees natural [H][W].  One in-place kernel converts when the need changes.
+// pnp_set_state, pnp_init_state) sees natural [H][W].  One kernel converts when the need changes (into the slice path's own
+// padded arrays; in place with PNP_SLICE_PAD_KB=0).
 static int state_order(pnp_ctx* c, bool sliced) {
     if (c->state_sliced == sliced) return PNP_OK;
     if (c->B > 0) {
-        hipError_t e = slice256_state_order(c->stream, c->z, c->w, c->B, sliced);
+        hipError_t e = slice256_state_order(c->slice, c->stream, c->z, c->w, c->B, sliced);
         if (e != hipSuccess) return fail(PNP_E_HIP, "state order: %s", hipGetErrorString(e));
     }
     c->state_sliced = sliced;

@@ -143,7 +143,7 @@ hipError_t slice256_prepare(Slice256*, hipStream_t s, const float2* y, const uin
 hipError_t slice256_run(Slice256*, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc, float dc_c,
                         ProxParams p, const FusedSchedule& sch);
 // in-place conversion of both state arrays [B][256][256] between natural order and slice order
-hipError_t slice256_state_order(hipStream_t s, float* z, float* w, int B, bool to_slice);
+hipError_t slice256_state_order(Slice256*, hipStream_t s, float* z, float* w, int B, bool to_slice);
 
 // fused 512x512 path (kernels_fused512.hip): same scheme with 32-lane transforms
 struct Fused512;

@@ -63,7 +63,7 @@ namespace pnp {
 __device__ c32 g_tws[256];
 
 struct SliceArgs {
-    float* z;                 // [B][256][256] state, updated in place
+    float* z;                 // state in slice order, state_stride floats per slice, updated in place
     float* w;
     float* x;                 // written by the last iteration
     const c32* Yh;            // [B] x YH3_SLICE
@@ -73,6 +73,8 @@ struct SliceArgs {
     int first, B, iters;      // slices [first, first + B) of the arrays; iterations of this launch
     int slice_xor;            // experiment knob (PNP_SLICE_XOR): workgroup b takes slice b ^ slice_xor (both below B)
     int flip;                 // workgroup b takes slice B - 1 - b: the launch starts with the slices the previous launch ended with
+    int state_stride;         // floats between consecutive slices of z / w (65536 + padding, Slice256::pad)
+    int yh_stride;            // complex elements between consecutive slices of Yh (YH3_SLICE + padding)
     float scale, c;
     ProxCoef prox;
     long long* prof;          // phase clock dump of a -DSLICE_PROF build (PNP_SLICE_PROF): [block][2 + 6 per iteration] of wall_clock64()
@@ -638,10 +640,10 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
     for (int sb = blockIdx.x; sb < p.B; sb += gridDim.x) {
         const int sx = ((sb ^ p.slice_xor) < p.B) ? (sb ^ p.slice_xor) : sb;
         const int slice = p.first + (p.flip ? p.B - 1 - sx : sx);
-        const size_t so = (size_t)slice * 65536;
+        const size_t so = (size_t)slice * p.state_stride;
         SliceBufs b;
-        b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + so, 65536 * 4);
-        b.yh = make_rsrc(p.Yh + (size_t)slice * YH3_SLICE, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
+        b.z = make_rsrc(p.z + so, 65536 * 4); b.w = make_rsrc(p.w + so, 65536 * 4); b.x = make_rsrc(p.x + (size_t)slice * 65536, 65536 * 4);
+        b.yh = make_rsrc(p.Yh + (size_t)slice * p.yh_stride, YH3_SLICE * 8); b.mh = make_rsrc(p.Mh + (size_t)slice * MH3_SLICE, MH3_SLICE * 4);
         b.ys = make_rsrc(p.Ys + (size_t)slice * 256, 256 * 8); b.ms = make_rsrc(p.Ms + (size_t)slice * 16, 16 * 4);
         c32 F[SL_SETS][16];
         // phase clocks exist only in a -DSLICE_PROF build (profiles/variants.sh): in the product they cost two registers
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(512) void k_slice(SliceArgs p) {
 // ------------------------------------------------------------------------------------------
 constexpr int SP_P = 17;                       // tile pitch (columns + 1)
 __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
-                                                  c32* Yh, uint32_t* Mh, c32* Ys, uint32_t* Ms) {
+                                                  c32* Yh, uint32_t* Mh, c32* Ys, uint32_t* Ms, int yh_stride) {
     __shared__ c32 yd[256 * SP_P], ym[256 * SP_P];           // direct tile [row][c], mirror tile [row][c] = y[row][-(16 m + c)]
     __shared__ uint8_t md[256 * SP_P], mm[256 * SP_P];
     const int tid = threadIdx.x, m = blockIdx.x, slice = blockIdx.y;
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* m
         const int g = lane >> 4, t = lane & 15, wv = 4 * (m & 1) + blk;
         c32 yh;
         (void)entry(t + 16 * j, 4 * blk + g, yh);
-        Yh[yh3_index(slice, set, j, wv, lane)] = yh;
+        Yh[(size_t)slice * yh_stride + yh3_index(0, set, j, wv, lane)] = yh;
     }
     {
         const int blk = tid >> 6, lane = tid & 63, g = lane >> 4, t = lane & 15, wv = 4 * (m & 1) + blk;
@@ -764,15 +766,18 @@ __global__ __launch_bounds__(256) void k_sprepare(const c32* y, const uint8_t* m
 }
 
 // ------------------------------------------------------------------------------------------
-// natural order <-> slice order of the state arrays (sl_state_index), in place: one block per (4 row pairs, slice), 128
+// natural order <-> slice order of the state arrays (sl_state_index), in place or between the caller-visible arrays and the
+// kernel's padded ones (Slice256::pad): one block per (4 row pairs, slice), 128
 // threads x 4 x 16 bytes per array.  Runs when a context's loops switch kernel families or the caller reads / writes the state.
 // ------------------------------------------------------------------------------------------
 template <bool TO_SLICE>
-__global__ __launch_bounds__(128) void k_state_order(float* z, float* w) {
+__global__ __launch_bounds__(128) void k_state_order(const float* sz, const float* sw, float* dz, float* dw, int src_stride, int dst_stride) {
     __shared__ float tile[2][2048];                       // one chunk = 4 row pairs = 8 image rows of the slice, both arrays
-    const size_t base = ((size_t)blockIdx.y * 32 + blockIdx.x) * 2048;
-    float4* pz = reinterpret_cast<float4*>(z + base);
-    float4* pw = reinterpret_cast<float4*>(w + base);
+    const size_t sbase = (size_t)blockIdx.y * src_stride + (size_t)blockIdx.x * 2048, dbase = (size_t)blockIdx.y * dst_stride + (size_t)blockIdx.x * 2048;
+    const float4* pz = reinterpret_cast<const float4*>(sz + sbase);
+    const float4* pw = reinterpret_cast<const float4*>(sw + sbase);
+    float4* qz = reinterpret_cast<float4*>(dz + dbase);
+    float4* qw = reinterpret_cast<float4*>(dw + dbase);
     float4 vz[4], vw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { vz[u] = pz[threadIdx.x + 128 * u]; vw[u] = pw[threadIdx.x + 128 * u]; }
@@ -798,16 +803,9 @@ __global__ __launch_bounds__(128) void k_state_order(float* z, float* w) {
             oz[k] = tile[0][at];
             ow[k] = tile[1][at];
         }
-        pz[i] = make_float4(oz[0], oz[1], oz[2], oz[3]);
-        pw[i] = make_float4(ow[0], ow[1], ow[2], ow[3]);
+        qz[i] = make_float4(oz[0], oz[1], oz[2], oz[3]);
+        qw[i] = make_float4(ow[0], ow[1], ow[2], ow[3]);
     }
-}
-
-hipError_t slice256_state_order(hipStream_t s, float* z, float* w, int B, bool to_slice) {
-    if (B <= 0) return hipSuccess;
-    if (to_slice) hipLaunchKernelGGL(k_state_order<true>, dim3(32, B), dim3(128), 0, s, z, w);
-    else          hipLaunchKernelGGL(k_state_order<false>, dim3(32, B), dim3(128), 0, s, z, w);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -816,6 +814,11 @@ hipError_t slice256_state_order(hipStream_t s, float* z, float* w, int B, bool t
 struct Slice256 {
     int Bmax = 0, cus = 0;
     int flip = 0;                            // direction of the next multi-round launch
+    // Slice stride of the kernel's own arrays.  pad > 0: the state in slice order lives in zs / ws with 65536 + pad floats per slice
+    // (the caller-visible z / w keep their contiguous natural layout); yh_pad likewise for the Hermitian table.  (PNP_SLICE_PAD_KB)
+    int pad = 0, yh_pad = 0;
+    float* zs = nullptr;
+    float* ws = nullptr;
     c32* Yh = nullptr;
     uint32_t* Mh = nullptr;
     c32* Ys = nullptr;
@@ -828,8 +831,22 @@ struct Slice256 {
 
 int slice256_cus(const Slice256* f) { return f && f->cus > 0 ? f->cus : 256; }
 
+hipError_t slice256_state_order(Slice256* f, hipStream_t s, float* z, float* w, int B, bool to_slice) {
+    if (B <= 0) return hipSuccess;
+    if (f && f->pad > 0) {                                 // between the natural arrays and the padded slice-order arrays
+        if (to_slice) hipLaunchKernelGGL(k_state_order<true>, dim3(32, B), dim3(128), 0, s, z, w, f->zs, f->ws, 65536, 65536 + f->pad);
+        else          hipLaunchKernelGGL(k_state_order<false>, dim3(32, B), dim3(128), 0, s, f->zs, f->ws, z, w, 65536 + f->pad, 65536);
+    } else {                                               // in place
+        if (to_slice) hipLaunchKernelGGL(k_state_order<true>, dim3(32, B), dim3(128), 0, s, z, w, z, w, 65536, 65536);
+        else          hipLaunchKernelGGL(k_state_order<false>, dim3(32, B), dim3(128), 0, s, z, w, z, w, 65536, 65536);
+    }
+    return hipGetLastError();
+}
+
 void slice256_destroy(Slice256* f) {
     if (!f) return;
+    if (f->zs) (void)hipFree(f->zs);
+    if (f->ws) (void)hipFree(f->ws);
     if (f->Yh) (void)hipFree(f->Yh);
     if (f->Mh) (void)hipFree(f->Mh);
     if (f->Ys) (void)hipFree(f->Ys);
@@ -845,7 +862,15 @@ void slice256_destroy(Slice256* f) {
 Slice256* slice256_create(int Bmax, hipError_t* err) {
     Slice256* f = new Slice256();
     f->Bmax = Bmax;
-    hipError_t e = hipMalloc((void**)&f->Yh, (size_t)Bmax * YH3_SLICE * sizeof(c32));
+    // 4 KiB of padding behind every slice of the state and of the table: with 256 KiB strides the streams of all resident
+    // workgroups sit on the same address bits above bit 17 at the same time; +2.4 % at the driver's 20 steps (9740 -> 9977 it/s,
+    // five alternating runs, variants_r03.log v28), +-0 at 100.  0 = round 3's in-place, unpadded form.
+    auto env_kb = [](const char* name, int dflt) { const char* ev = getenv(name); const int v = ev ? atoi(ev) : dflt; return v > 0 ? v : 0; };
+    f->pad = env_kb("PNP_SLICE_PAD_KB", 4) * 256;             // floats
+    f->yh_pad = env_kb("PNP_SLICE_YH_PAD_KB", 4) * 128;       // complex elements
+    hipError_t e = hipMalloc((void**)&f->Yh, (size_t)Bmax * (YH3_SLICE + f->yh_pad) * sizeof(c32));
+    if (e == hipSuccess && f->pad > 0) e = hipMalloc((void**)&f->zs, (size_t)Bmax * (65536 + f->pad) * sizeof(float));
+    if (e == hipSuccess && f->pad > 0) e = hipMalloc((void**)&f->ws, (size_t)Bmax * (65536 + f->pad) * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&f->Mh, (size_t)Bmax * MH3_SLICE * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&f->Ys, (size_t)Bmax * 256 * sizeof(c32));
     if (e == hipSuccess) e = hipMalloc((void**)&f->Ms, (size_t)Bmax * 16 * sizeof(uint32_t));
@@ -876,7 +901,7 @@ Slice256* slice256_create(int Bmax, hipError_t* err) {
 hipError_t slice256_prepare(Slice256* f, hipStream_t s, const float2* y, const uint8_t* mask_bank, const int32_t* mask_id, int B) {
     if (B > f->Bmax) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_sprepare, dim3(9, B), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank, mask_id,
-                       f->Yh, f->Mh, f->Ys, f->Ms);
+                       f->Yh, f->Mh, f->Ys, f->Ms, (int)YH3_SLICE + f->yh_pad);
     return hipGetLastError();
 }
 
@@ -899,7 +924,8 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
                         ProxParams pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
     SliceArgs a;
-    a.z = z; a.w = w; a.x = x; a.Yh = f->Yh; a.Mh = f->Mh; a.Ys = f->Ys; a.Ms = f->Ms;
+    a.z = f->pad > 0 ? f->zs : z; a.w = f->pad > 0 ? f->ws : w; a.x = x; a.Yh = f->Yh;
+    a.state_stride = 65536 + f->pad; a.yh_stride = (int)YH3_SLICE + f->yh_pad; a.Mh = f->Mh; a.Ys = f->Ys; a.Ms = f->Ms;
     a.first = 0; a.B = B; a.iters = iters; a.scale = 1.0f / 65536.0f; a.c = dc_c;
     a.prox.thr = pp.thr; a.prox.c1 = pp.c1; a.prox.c2 = pp.c2; a.prox.c3 = pp.c3; a.prox.ib = pp.ib;
     a.prof = nullptr;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: ab_env.sh "<bench args>" reps VAR val1 val2 ...
+# A/B of an environment knob on ONE box, interleaved:   bash profiles/ab_env.sh "<bench args>" <reps> <VAR> <value> [<value> ...]
+# (a value may carry further assignments: "4 PNP_SLICE_YH_PAD_KB=4")
 ARGS=$1; REPS=$2; VAR=$3; shift 3
 export PNP_BENCH_CACHE=/tmp/pb
 for rep in $(seq 1 $REPS); do for v in "$@"; do

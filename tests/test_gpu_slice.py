@@ -155,6 +155,35 @@ def test_slice_path_at_every_batch_shape(P, B, monkeypatch):
         assert rel_l2(res['1'][3][b], O.admm_l1(y128, masks[mid[b]], 5)) <= 2e-6
 
 
+def test_padded_and_unpadded_slice_strides_are_bit_identical(P, monkeypatch):
+    """The slice path keeps its state and its table with 4 KiB of padding per slice (PNP_SLICE_PAD_KB / PNP_SLICE_YH_PAD_KB,
+    kernels_slice256.hip: slice256_create); 0 is the in-place, unpadded form.  Same arithmetic on the same values: x, z and w
+    agree to the bit -- across a state hand-over (get_state / set_state go through the natural order) and a batch that
+    ends in a partial round."""
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    B = 259
+    masks = S.reference_masks()['Q_Random30'].astype(np.uint8)[None]
+    img, noise = S.batch(3, B)
+    monkeypatch.setenv('PNP_SLICE', '1')
+    res = {}
+    for pad, yh in (('0', '0'), ('4', '4'), ('1', '16')):
+        monkeypatch.setenv('PNP_SLICE_PAD_KB', pad)
+        monkeypatch.setenv('PNP_SLICE_YH_PAD_KB', yh)
+        with P.Engine(256, 256, Bmax=B) as eng:
+            eng.synthesize(img, noise, masks, np.zeros(B, np.int32))
+            eng.init_state()
+            eng.admm_cnc(3, 0.45, 0.5, 0.05, 64)
+            z, w = eng.get_state()                      # slice order -> natural
+            eng.set_state(z, w)                         # natural; the next run converts again
+            eng.admm_cnc(4, 0.45, 0.5, 0.05, 64)
+            assert eng.path_name == 'slice'
+            res[(pad, yh)] = (eng.x(),) + tuple(eng.get_state())
+    ref = res[('0', '0')]
+    for key, got in res.items():
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), key
+
+
 def test_chip_filling_run_matches_the_two_launch_path(P, monkeypatch):
     """512 slices (two rounds on every compute unit, the shape bench.py times), 48 iterations of the slice-resident
     kernel, EVERY slice checked against the two-launch path every 4 iterations.  Both paths share the arithmetic cores
