@@ -91,6 +91,29 @@ def test_slice_resident_kernel_stays_off_the_cliff(asm):
         assert i['codeLenInByte'] <= 96 * 1024, (name, i)
 
 
+def test_slice_resident_kernel_instruction_budget(asm):
+    """What round 3's two passes over the compiled ISA removed must not come back unnoticed with a compiler bump or an edit
+    (DESIGN.md 4.1): the conservative hazard `s_nop`s behind inline asm (294 per wave-iteration before the packed complex
+    product became one asm statement), hipcc's scalarised forms of the pointwise update (four `v_sub_f32` per access, `v_and`
+    + packed add for |a| + w), per-access `v_add_u32` for LDS offsets beyond the 16-bit immediate, the packed column's selects
+    in all eight waves.  Budgets = the whole kernel (prologue + loop + the last iteration's extras), 8-10 % above today's
+    counts (CNC: 6478 vector instructions of which 4600 packed, 191 s_nop, 48 v_sub_f32, 165 v_cndmask)."""
+    ks = {n: k for n, k in kernels_of(asm['kernels_slice256.hip']).items() if 'k_slice' in n}
+    cnc = [k for n, k in ks.items() if 'ILi2E' in n]
+    assert len(cnc) == 1, sorted(ks)
+    body = cnc[0]['body']
+    valu = [i for i in body if i.startswith('v_')]
+    count = lambda pre: sum(1 for i in body if i.startswith(pre))
+    stats = {'valu': len(valu), 'packed': count('v_pk_'), 's_nop': count('s_nop'), 'v_sub_f32': count('v_sub_f32'),
+             'v_cndmask': count('v_cndmask'), 'v_mov_b32': count('v_mov_b32'), 'ds': count('ds_'), 'scratch': count('scratch_')}
+    assert stats['scratch'] == 0, stats
+    assert stats['valu'] <= 7000, stats
+    assert stats['s_nop'] <= 260, stats
+    assert stats['v_sub_f32'] <= 120, stats                          # 342 with the scalarised v = z - w
+    assert stats['v_cndmask'] <= 230, stats
+    assert stats['packed'] >= 0.62 * stats['valu'], stats            # the transforms stay on packed fp32
+
+
 def test_512_column_kernel_register_budget(asm):
     ks = {n: k for n, k in kernels_of(asm['kernels_fused512.hip']).items() if 'k5_cols' in n}
     assert ks
