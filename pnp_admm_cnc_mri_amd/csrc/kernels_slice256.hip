@@ -309,7 +309,10 @@ __device__ __forceinline__ void pointwise_q(const SliceBufs& b, const ProxCoef& 
         f2 u[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            if (!u_first) w[jj] = w[jj] - (w[jj] - clamp2(w[jj], pc.thr));
+            if (!u_first) {                            // wave-uniform: a scalar branch (the asm keeps hipcc from turning it into two selects per pair)
+                asm volatile("");
+                w[jj] = w[jj] - (w[jj] - clamp2(w[jj], pc.thr));
+            }
             u[jj] = SL_X_PLUS(jj ? a1 : a0, w[jj]);
             z[jj] = u[jj] - clamp2(u[jj], pc.thr);
             w[jj] = u[jj] - z[jj];
