@@ -39,6 +39,12 @@ B_PER_GPU = 512
 PRESET = dict(alpha=0.45, lambda1=0.5, reo=0.05, b=64)          # S4:176
 ALG_BYTES_PER_PIXEL = 57
 HBM_PEAK_GBS = 8000.0                                              # MI355X_MICROARCH.md
+# Bytes per pixel and slice-iteration each kernel family must move BY DESIGN (DESIGN.md sections 3, 4), float32;
+# a double-precision context doubles them.  slice: z, w read + written (16) + Hermitian half-plane table (4), ADMM_L1
+# single-state form 8 + 4; fused 256: + the transposed field of two slices per complex transform out and back (16);
+# fused 512: 36.4 measured layout; generic: the plain c2c contract.
+OWN_BYTES_PER_PIXEL = {('slice', 'cnc'): 20.0, ('slice', 'l1'): 12.0, ('fused', 'cnc'): 36.0, ('fused', 'l1'): 28.0,
+                       ('generic', 'cnc'): 57.0, ('generic', 'l1'): 57.0}
 
 
 def cpu_baseline(masks, mask_id, budget_s=20.0, iters=100):
@@ -195,6 +201,11 @@ def main():
                     help='--gpus N without torchrun: seconds after which hanging rank processes are killed (exit 124)')
     ap.add_argument('--no-f64-record', action='store_true',
                     help="skip the double-precision engine's sub-record (N = 1, headline configuration only)")
+    ap.add_argument('--sustain-s', type=float, default=2.0,
+                    help='seconds of the `sustained` sub-record: back-to-back calls of --steps iterations for this long '
+                         '(after half as long a pre-heat), HIP events over the whole span; 0 = off')
+    ap.add_argument('--sustain-reinit', type=int, default=0,
+                    help='sustained record: set the state back to z0, w0 every this many iterations (0 = keep iterating)')
     ap.add_argument('--rehearse-gloo', action='store_true',
                     help='rehearsal of the N>1 launch path on a box with ONE GPU: gloo backend, all ranks on cuda:0')
     args = ap.parse_args()
@@ -258,6 +269,7 @@ def main():
         eng.upload(y32, masks, mask_id)
         del y32
     eng.init_state()
+    eng.prepare_loops()                                               # per-problem tables of the loop kernels: never inside a timed region
 
     def run(e, n):
         if args.solver == 'cnc':
@@ -293,8 +305,33 @@ def main():
     # the one collective of the job: gather x on rank 0 over RCCL (timed apart from the steps)
     gather_ms = None
     x_dev = torch.empty((B, H, W), dtype=torch.float64 if args.precision == 'f64' else torch.float32, device='cuda')
-    eng.x(out=x_dev)
+    eng.x(out=x_dev)                                                  # x after exactly W + K iterations: what checksum / parity / gather see
     eng.sync()
+
+    def sustained(e, seconds, ms_per_step_burst):
+        """Back-to-back calls of K steps for `seconds` s after a pre-heat of half that, no host sync in between:
+        HIP events on the kernels' stream around the whole timed span.  With --sustain-reinit R the state is set back
+        to z0 = |ifft2(y)|, w0 = 0 every R iterations, as a job that works through batch after batch would
+        (the two initialisation kernels are then inside the span; only iterations are counted).  -> (steps, span_ms)."""
+        per_call_ms = max(ms_per_step_burst * args.steps * 1.35, 1e-3)   # the settled chip runs ~1.2-1.3x slower than a burst
+        n_heat = max(1, int(seconds * 0.5 * 1e3 / per_call_ms))
+        n_timed = max(1, int(seconds * 1e3 / per_call_ms))
+        every = max(1, args.sustain_reinit // args.steps) if args.sustain_reinit > 0 else 0
+
+        def calls(n):
+            for i in range(n):
+                if every and i % every == 0:
+                    e.init_state()
+                run(e, args.steps)
+        calls(n_heat)
+        e.timer_start()
+        calls(n_timed)
+        return n_timed * args.steps, e.timer_stop()
+
+    sus = None
+    if args.sustain_s > 0:
+        sus_steps, sus_ms = sustained(eng, args.sustain_s, ev_ms / args.steps)
+        sus = [float(sus_steps), float(sus_ms)]
     if dist is not None:
         from pnp_admm_cnc_mri_amd import sharding
         torch.cuda.synchronize()
@@ -310,9 +347,18 @@ def main():
         assert (x_all is not None) == (rank == 0)
         if rank == 0:
             assert tuple(x_all.shape) == (world * B, H, W) and torch.equal(x_all[:B].to(x_dev.device), x_dev)
-        t = torch.tensor([wall_ms, ev_ms, gather_ms], dtype=torch.float64, device='cpu' if args.rehearse_gloo else 'cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_ms, ev_ms, gather_ms = (float(v) for v in t.cpu())
+        dev_t = 'cpu' if args.rehearse_gloo else 'cuda'
+        mine = torch.tensor([wall_ms, ev_ms, gather_ms, sus[1] / sus[0] if sus else 0.0], dtype=torch.float64, device=dev_t)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                    # every rank's own clocks: a slow GPU shows in the line
+        per_rank = torch.stack(every).cpu()
+        wall_ms, ev_ms, gather_ms = (float(v) for v in per_rank[:, :3].max(dim=0).values)   # the job's time: MAX over ranks
+        if sus:
+            sus = [sus[0], float(per_rank[:, 3].max()) * sus[0]]      # slowest rank's time per step x this rank's steps (equal on all ranks up to the burst estimate)
+    per_rank_ms = None if dist is None else {'ms_per_step': [float(v) / args.steps for v in per_rank[:, 0]],
+                                             'hip_event_ms_per_step': [float(v) / args.steps for v in per_rank[:, 1]],
+                                             'gather_ms': [float(v) for v in per_rank[:, 2]],
+                                             'sustained_ms_per_step': [float(v) for v in per_rank[:, 3]] if sus else None}
     checksum = float(x_dev.double().sum())
     finite = bool(torch.isfinite(x_dev).all())
 
@@ -360,9 +406,9 @@ def main():
                           'ms_per_step': w64 / args.steps, 'hip_event_ms_per_step': ev64 / args.steps,
                           'dtype': 'f64', 'path': e64.path_name, 'rel_l2_vs_oracle': rel(x64), 'slices': picks,
                           'iterations': n_it,
-                          'frac': ALG_BYTES_PER_PIXEL * H * W * B / (ev64 / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          'traffic': t64,
-                          'frac_measured': None if t64 is None else t64 / (ev64 / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          'frac': None if t64 is None else t64 / (ev64 / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'frac_contract_57N': ALG_BYTES_PER_PIXEL * H * W * B / (ev64 / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'traffic': t64}
             del x64
             e64.close()
         del y_all
@@ -372,7 +418,6 @@ def main():
         ms_per_step = wall_ms / K
         value = world * K / (wall_ms * 1e-3) * (B / B_PER_GPU)
         alg_bytes = ALG_BYTES_PER_PIXEL * H * W * B * K
-        achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
         # per-iteration HBM bytes of exactly this configuration from rocprofv3 --pmc (profiles/summarize.py)
         traffic, traffic_src = None, None
         tkey = '%s:%s:%d:%s:b%d' % (eng.path_name, args.solver, H, args.precision, B)
@@ -388,6 +433,23 @@ def main():
         if args.generic or eng.path_name == 'generic':
             sched = {'queues': 1, 'mixed': 0, 'chunk': 0}
         ev_s_per_it = ev_ms * 1e-3 / K
+        contract = alg_bytes / K                                            # 57 N B bytes per batched iteration
+        own = OWN_BYTES_PER_PIXEL.get((eng.path_name, args.solver))
+        own = None if own is None else own * H * W * B * (2 if args.precision == 'f64' else 1)
+        # roofline.achieved / frac: the bytes the kernels REALLY move per iteration (PMC, committed per configuration) over the
+        # HIP-event time -- a physical fraction of the 8 TB/s peak.  Where no PMC figure is committed for a configuration the
+        # kernel family's own algorithmic bytes stand in (the PMC figure is 1.06x that on the headline path).
+        phys_bytes, phys_kind = (traffic, 'pmc') if traffic is not None else (own, 'own_algorithmic') if own is not None else (contract, 'contract_57N')
+        achieved = phys_bytes / ev_s_per_it / 1e9
+        sustained_rec = None
+        if sus:
+            s_per_it = sus[1] * 1e-3 / sus[0]
+            sustained_rec = {'value': world / s_per_it * (B / B_PER_GPU), 'unit': 'it/s (512-slice batches)',
+                             'ms_per_step': s_per_it * 1e3, 'steps': int(sus[0]), 'steps_per_call': K, 'span_s': sus[1] * 1e-3,
+                             'preheat_s': args.sustain_s * 0.5, 'reinit_every': args.sustain_reinit, 'frac': phys_bytes / s_per_it / 1e9 / HBM_PEAK_GBS,
+                             'frac_contract_57N': contract / s_per_it / 1e9 / HBM_PEAK_GBS,
+                             'timing': 'HIP events on the kernels\' stream around back-to-back calls, no host sync inside; '
+                                       'N > 1: the slowest rank\'s time per step'}
         line = {
             'metric': 'ADMM iterations/sec on %dx%d complex64 slices (batch=512)' % (H, W),
             'value': value, 'unit': 'it/s (512-slice batches)',
@@ -404,22 +466,28 @@ def main():
                        'mixed_row_col_launches': bool(sched['mixed'])},
             'slice_iterations_per_s': value * B_PER_GPU,
             'hip_event_ms_per_step': ev_ms / K,
+            'sustained': sustained_rec,
+            'per_rank': per_rank_ms,
             'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,
             'parity': parity, 'f64': f64_record,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         # the physically meaningful pair: bytes the kernels really move (PMC) over the same time
-                         'achieved_measured': None if traffic is None else traffic / ev_s_per_it / 1e9,
-                         'frac_measured': None if traffic is None else traffic / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
-                         'traffic_over_algorithmic': None if traffic is None else traffic / (alg_bytes / K),
+                         'bytes_per_iteration': phys_bytes, 'bytes_from': phys_kind,
+                         'frac_own_algorithmic': None if own is None else own / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
+                         'own_algorithmic_bytes_per_iteration': own,
+                         'frac_contract_57N': contract / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
+                         'achieved_contract_57N': contract / ev_s_per_it / 1e9,
+                         'contract_bytes_per_iteration': contract,
+                         'traffic_over_contract': None if traffic is None else traffic / contract,
+                         'traffic_over_own_algorithmic': None if (traffic is None or own is None) else traffic / own,
                          'traffic_from': traffic_src,
                          'traffic_measured_in_this_run': False,       # PMC passes on the builder's box, committed under profiles/
-                         'note': 'achieved = 57*H*W*B algorithmic bytes per iteration (SURVEY.md 8d: plain c2c float32 '
-                                 'formulation) / HIP-event time per iteration on the kernels\' stream; it exceeds the peak '
-                                 'because the kernels move fewer bytes than that formulation (slice-resident path: z, w and the '
-                                 'Hermitian half-plane table only, the transposed field never leaves the compute unit; fused path: '
-                                 'two real slices per complex FFT, Hermitian half plane).  achieved_measured / frac_measured = '
-                                 'PMC-measured HBM bytes per iteration (traffic, FETCH_SIZE x2 + WRITE_SIZE) / the same time.'},
+                         'note': 'achieved / frac = HBM bytes the kernels move per batched iteration (traffic: rocprofv3 PMC, '
+                                 'FETCH_SIZE x2 + WRITE_SIZE, of exactly this configuration) / HIP-event time per iteration on the '
+                                 'kernels\' stream.  frac_contract_57N prices the same time against SURVEY.md 8(d)\'s 57*H*W*B bytes '
+                                 'of the plain c2c float32 formulation; it exceeds 1 because the kernels move fewer bytes than that '
+                                 '(slice-resident path: z, w and the Hermitian half-plane table only, the transposed field never '
+                                 'leaves the compute unit; fused path: two real slices per complex FFT, Hermitian half plane).'},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)

@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   7
+#define PNP_ABI_VERSION   8
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -65,7 +65,9 @@ int pnp_set_fast_path(pnp_ctx* ctx, int enable);
  *                   default -- at 512x512 and for the double-precision 256x256 engine the chunks go round-robin to 4 queues
  *                   (16 resp. 24 slices each with queues >= 2; 48 resp. 96 on one queue), so the chunks in flight fit the
  *                   256 MiB Infinity Cache for a whole run; whole batch otherwise; <0: whole batch
- * Environment defaults read at pnp_ctx_create: PNP_FUSED_STREAMS, PNP_FUSED_SCHED, PNP_FUSED_CHUNK. */
+ * Environment defaults read (once, range-checked: a malformed value fails pnp_ctx_create with PNP_E_ARG) at pnp_ctx_create:
+ * PNP_FUSED_STREAMS, PNP_FUSED_SCHED, PNP_FUSED_CHUNK; PNP_SLICE (0 / 1), PNP_SLICE_MIN_B, PNP_SLICE_PAD_KB, PNP_SLICE_YH_PAD_KB,
+ * PNP_FUSED_COLS.  The experiment knobs of the profiling scripts exist only in -DPNP_EXPERIMENT_KNOBS builds. */
 int pnp_set_schedule(pnp_ctx* ctx, int queues, int mixed_launches, int chunk);
 /* the schedule in force (any pointer may be NULL) */
 int pnp_get_schedule(pnp_ctx* ctx, int* queues, int* mixed_launches, int* chunk);
@@ -98,6 +100,11 @@ int pnp_init_state(pnp_ctx* ctx);
 /* overwrite / read the ctx-owned ADMM state z, w ([B][H][W] float32 each); NULL skips one. */
 int pnp_set_state(pnp_ctx* ctx, const float* z, const float* w, int on_device);
 int pnp_get_state(pnp_ctx* ctx, float* z, float* w, int on_device);
+
+/* Build now the per-problem tables the whole loops below will use (256x256 float contexts build them on the first loop call
+ * otherwise: the slice-resident tables only when a loop really takes that path, so that step-wise PnP users never pay for
+ * them).  Optional; benchmarks call it to keep table building out of a timed region without warm-up.  New in ABI 8. */
+int pnp_prepare_loops(pnp_ctx* ctx);
 
 /* ---- whole loops on the ctx-owned state (no host sync inside) ----------------------------- */
 /* iters = 0: the loop body never runs; x is set to the current z (the reference's x = |ifft2(y)| = z0
@@ -156,15 +163,31 @@ int pnp_ssim(pnp_ctx* ctx, const float* x_dev, const uint8_t* gt, int gt_on_devi
  * ~1.08x per iteration, so this is the mode in which 100-iteration CNC runs meet 1e-5 end to end.
  * 256x256 runs on the fused two-launch kernels in double (a throughput path: ~2500 batched
  * iterations/s at 512 slices); other shapes on the generic kernels in double.
- * The step-wise / operator entry points are float-only and return PNP_E_STATE on such a context. */
+ * Since ABI 8 everything the whole-solver entry points need exists in double (synthesis, metrics, SSIM), so
+ * ADMM_L1 / ADMM_CNC (precision='f64') run the reference's own arithmetic end to end; the step-wise / operator entry points
+ * (PnP path: the reference itself switches to float32 there, S6:273-285) are float-only and return PNP_E_STATE on such a context. */
 int pnp_ctx_create_f64(int device, int H, int W, int Bmax, pnp_ctx** out);
 /* y: [B][H][W] complex128 (interleaved doubles); masks as pnp_upload_problem. */
 int pnp_upload_problem_f64(pnp_ctx* ctx, const double* y, const uint8_t* mask_bank,
                            const int32_t* mask_id, int B, int K, int on_device);
+/* y = fft2(img)*mask + noise in double (S4:102): img [B][H][W] float32 (the reference's img_L is float32,
+ * utils/utils_image.py:181-182), noise complex128 [H][W] (noise_per_slice = 0: the reference's noises.mat) or [B][H][W].
+ * The float32 image is widened exactly and transformed in double; NumPy >= 2 runs this one transform in complex64 before
+ * promoting it, so the two y differ by that transform's float32 round-off (~1e-7 relative), which the committed CNC presets
+ * amplify to ~2e-6 after 50 iterations -- inside the 1e-5 bar (tests/test_gpu_f64.py).  New in ABI 8. */
+int pnp_synthesize_problem_f64(pnp_ctx* ctx, const float* img, const double* noise, int noise_per_slice,
+                               const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device);
+/* copy the ctx's y back ([B][H][W] complex128).  New in ABI 8. */
+int pnp_download_y_f64(pnp_ctx* ctx, double* y, int on_device);
 int pnp_set_state_f64(pnp_ctx* ctx, const double* z, const double* w, int on_device);
 int pnp_get_state_f64(pnp_ctx* ctx, double* z, double* w, int on_device);
 int pnp_download_x_f64(pnp_ctx* ctx, double* x, int on_device);
 int pnp_is_f64(pnp_ctx* ctx);
+/* pnp_metrics / pnp_ssim on a double-precision context: img_E = x*255 formed in double from the float64 x, exactly as the
+ * reference does (S4:139, 149-151).  x_dev = NULL: the ctx-owned x.  New in ABI 8. */
+int pnp_metrics_f64(pnp_ctx* ctx, const double* x_dev, const uint8_t* gt, int gt_on_device,
+                    double* psnr_host, double* re_host);
+int pnp_ssim_f64(pnp_ctx* ctx, const double* x_dev, const uint8_t* gt, int gt_on_device, double* ssim_host);
 
 /* ---- timing on the ctx stream (HIP events) ------------------------------------------------ */
 int pnp_timer_start(pnp_ctx* ctx);

@@ -58,6 +58,11 @@ SIGNATURES = {
     'pnp_get_state_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int]),
     'pnp_download_x_f64': (C.c_int, [ctx_p, _vp, C.c_int]),
     'pnp_is_f64': (C.c_int, [ctx_p]),
+    'pnp_synthesize_problem_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    'pnp_download_y_f64': (C.c_int, [ctx_p, _vp, C.c_int]),
+    'pnp_metrics_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p, c_double_p]),
+    'pnp_ssim_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p]),
+    'pnp_prepare_loops': (C.c_int, [ctx_p]),
     'pnp_ssim': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p]),
     'pnp_timer_start': (C.c_int, [ctx_p]),
     'pnp_timer_stop': (C.c_int, [ctx_p, c_float_p]),
@@ -65,7 +70,7 @@ SIGNATURES = {
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -68,9 +68,10 @@ hipError_t launch_combine(hipStream_t s, const float* z, const float* x, const f
                           float* t, float c1, float c2, float c3, size_t n);
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* o, size_t n);
 hipError_t launch_dual_clamp(hipStream_t s, float* x, float* z, float* w, size_t n);
-hipError_t launch_metrics(hipStream_t s, const float* x, const uint8_t* gt, double* acc /*[B][2]*/, int B, int N);
+template <typename X> hipError_t launch_metrics(hipStream_t s, const X* x, const uint8_t* gt, double* acc /*[B][2]*/, int B, int N);
 hipError_t upload_gauss();
-hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double* partial /*[B][tiles]*/, int B, int H, int W);
+template <typename X> hipError_t launch_ssim(hipStream_t s, const X* x, const uint8_t* gt, double* partial /*[B][tiles]*/, int B, int H, int W);
+hipError_t launch_widen(hipStream_t s, const float* in, double* out, size_t n);      // float -> double, n % 4 == 0
 
 // How the fused loops are scheduled (scheduling only: results are bit-identical for every setting).
 struct FusedSchedule {
@@ -79,6 +80,13 @@ struct FusedSchedule {
     int chunk = 0;          // >0: a queue finishes all iterations on `chunk` slices before its next chunk; 0: the path's default
                             // (chunk_plan below); <0: off (whole batch / two halves)
     int l1_two_state = 0;   // test hook: ADMM_L1 keeps z and w every iteration instead of u only
+    // Experiment knobs.  They stay at these defaults unless the library is built with -DPNP_EXPERIMENT_KNOBS (profiles/variants.sh
+    // does); such a build reads them from the environment ONCE, at pnp_ctx_create (api.hip, read_knobs), range-checked.
+    int chunk_queues = 0;   // >0: queues of the chunked schedules           (PNP_F512_QUEUES / PNP_F256S_QUEUES)
+    int slice_xor = 0;      // slice <-> workgroup permutation b ^ xor          (PNP_SLICE_XOR)
+    int slice_queues = 1;   // slice-resident run cut over HIP queues ...       (PNP_SLICE_QUEUES)
+    int slice_segment = 0;  // ... and into launches of this many iterations    (PNP_SLICE_SEGMENT)
+    int slice_flip = 1;     // every other multi-round call walks the batch backwards (PNP_SLICE_FLIP)
 };
 
 // Chunked schedules of the 512x512 loops and of the split-chain (double) 256x256 loops: a queue runs ALL iterations of a run on
@@ -135,7 +143,7 @@ template <typename R> hipError_t    fused256s_dc(Fused256S<R>*, hipStream_t s, c
 
 // slice-resident 256x256 path (kernels_slice256.hip): one workgroup keeps one slice in registers for a whole run
 struct Slice256;
-Slice256*  slice256_create(int Bmax, hipError_t* err);
+Slice256*  slice256_create(int Bmax, int pad_kb /* state */, int yh_pad_kb /* table */, hipError_t* err);
 void       slice256_destroy(Slice256*);
 int        slice256_cus(const Slice256*);     // compute units of the device (= slices in flight)
 hipError_t slice256_prepare(Slice256*, hipStream_t s, const float2* y, const uint8_t* mask_bank, const int32_t* mask_id, int B);

@@ -779,9 +779,8 @@ hipError_t fused256s_run(Fused256S<R>* f, hipStream_t s, R* z, R* w, R* x, int B
     if (iters <= 0) return hipSuccess;
     const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
     // chunked round-robin schedule: internal.h, chunk_plan.  sch.chunk < 0 (PNP_FUSED_CHUNK=-1): two halves of the batch on
-    // two queues (the round-1 schedule); PNP_F256S_QUEUES overrides the number of queues (experiments).
-    const char* ev = getenv("PNP_F256S_QUEUES");
-    const ChunkPlan plan = chunk_plan(B, sch, false, sizeof(R) == 8, ev ? atoi(ev) : 0);
+    // two queues (the round-1 schedule); sch.chunk_queues overrides the number of queues (experiment builds).
+    const ChunkPlan plan = chunk_plan(B, sch, false, sizeof(R) == 8, sch.chunk_queues);
     const int Q = plan.queues, chunk = plan.chunk;
     hipError_t e = hipSuccess;
     if (Q < 2 || B <= chunk) {

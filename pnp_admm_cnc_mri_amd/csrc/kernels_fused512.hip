@@ -366,11 +366,6 @@ static hipError_t run5_chunk(Fused512* f, hipStream_t s, float* z, float* w, flo
     return e;
 }
 
-static int env_queues() {
-    const char* v = getenv("PNP_F512_QUEUES");
-    return v ? atoi(v) : 0;
-}
-
 hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x, int B, int iters, bool cnc,
                         float dc_c, ProxParams pp, const FusedSchedule& sch) {
     if (iters <= 0) return hipSuccess;
@@ -380,8 +375,8 @@ hipError_t fused512_run(Fused512* f, hipStream_t s, float* z, float* w, float* x
     // the row body down to 2 waves/SIMD in a mixed launch), so the queue / mixed knobs of
     // FusedSchedule apply to the 256x256 path only.
     // chunked round-robin schedule: internal.h, chunk_plan (4 MiB per slice: z, w, T, Yh).  sch.chunk (PNP_FUSED_CHUNK) overrides
-    // the chunk size, < 0 = whole batch; PNP_F512_QUEUES overrides the number of queues (experiments).
-    const ChunkPlan plan = chunk_plan(B, sch, true, false, env_queues());
+    // the chunk size, < 0 = whole batch; sch.chunk_queues overrides the number of queues (experiment builds).
+    const ChunkPlan plan = chunk_plan(B, sch, true, false, sch.chunk_queues);
     const int Q = plan.queues, chunk = plan.chunk;
     hipError_t e = hipSuccess;
     if (Q < 2 || B <= chunk) {

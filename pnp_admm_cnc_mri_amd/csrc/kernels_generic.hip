@@ -578,9 +578,18 @@ static hipError_t launch_cols32_any(hipStream_t s, int W, bool pre, ColMid mid, 
     if (pre && !post && mid == MID_MASK_ADD)  return launch_cols32<true, MID_MASK_ADD, false>(s, W, a);
     return hipErrorInvalidValue;
 }
+// A/B knob of experiment builds (-DPNP_EXPERIMENT_KNOBS): PNP_GENERIC_STOCKHAM selects the four-stage LDS kernel for float too
+static inline bool generic_stockham() {
+#ifdef PNP_EXPERIMENT_KNOBS
+    static const bool on = getenv("PNP_GENERIC_STOCKHAM") != nullptr;
+    return on;
+#else
+    return false;
+#endif
+}
 template <typename R> static hipError_t cols32_or_stockham(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a);
 template <> hipError_t cols32_or_stockham<float>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
-    static const bool stockham = getenv("PNP_GENERIC_STOCKHAM") != nullptr;
+    const bool stockham = generic_stockham();
     return stockham ? launch_cols_n<512>(s, W, pre, mid, post, a) : launch_cols32_any(s, W, pre, mid, post, a);
 }
 template <> hipError_t cols32_or_stockham<double>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<double>& a) {
@@ -589,7 +598,7 @@ template <> hipError_t cols32_or_stockham<double>(hipStream_t s, int W, bool pre
 
 template <typename R> static hipError_t cols16_or_stockham(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<R>& a);
 template <> hipError_t cols16_or_stockham<float>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<float>& a) {
-    static const bool stockham = getenv("PNP_GENERIC_STOCKHAM") != nullptr;      // developer knob: the four-stage LDS kernel (A/B runs)
+    const bool stockham = generic_stockham();
     return stockham ? launch_cols_n<256>(s, W, pre, mid, post, a) : launch_cols16_any(s, W, pre, mid, post, a);
 }
 template <> hipError_t cols16_or_stockham<double>(hipStream_t s, int W, bool pre, ColMid mid, bool post, const ColArgsT<double>& a) {
@@ -686,9 +695,10 @@ hipError_t launch_dual_clamp(hipStream_t s, float* x, float* z, float* w, size_t
 // metrics: per slice sum((255 x - gt)^2) and sum(gt^2) in double        (utils_image.py:543-636)
 // one workgroup per slice; wave shuffle reduction then LDS across the 4 waves
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_metrics(const float* x, const uint8_t* gt, double* acc, int N) {
+template <typename X>
+__global__ __launch_bounds__(256) void k_metrics(const X* x, const uint8_t* gt, double* acc, int N) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* xb = x + (size_t)b * N;
+    const X* xb = x + (size_t)b * N;
     const uint8_t* gb = gt + (size_t)b * N;
     double se = 0.0, sg = 0.0;
     for (int i = tid; i < N; i += 256) {
@@ -704,10 +714,13 @@ __global__ __launch_bounds__(256) void k_metrics(const float* x, const uint8_t* 
     if (tid == 0) { acc[2 * b] = s1[0] + s1[1] + s1[2] + s1[3]; acc[2 * b + 1] = s2[0] + s2[1] + s2[2] + s2[3]; }
 }
 
-hipError_t launch_metrics(hipStream_t s, const float* x, const uint8_t* gt, double* acc, int B, int N) {
-    hipLaunchKernelGGL(k_metrics, dim3(B), dim3(256), 0, s, x, gt, acc, N);
+template <typename X>
+hipError_t launch_metrics(hipStream_t s, const X* x, const uint8_t* gt, double* acc, int B, int N) {
+    hipLaunchKernelGGL(k_metrics<X>, dim3(B), dim3(256), 0, s, x, gt, acc, N);
     return hipGetLastError();
 }
+template hipError_t launch_metrics<float>(hipStream_t, const float*, const uint8_t*, double*, int, int);
+template hipError_t launch_metrics<double>(hipStream_t, const double*, const uint8_t*, double*, int, int);
 
 // ------------------------------------------------------------------------------------------
 // SSIM (utils/utils_image.py:593-615): 11-tap Gaussian (sigma 1.5) on the valid region, in double.
@@ -724,14 +737,15 @@ hipError_t upload_gauss() {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g));
 }
 
-__global__ __launch_bounds__(256) void k_ssim(const float* x, const uint8_t* gt, double* partial, int H, int W, int tiles_x, int tiles_y) {
+template <typename X>
+__global__ __launch_bounds__(256) void k_ssim(const X* x, const uint8_t* gt, double* partial, int H, int W, int tiles_x, int tiles_y) {
     __shared__ double sx[26][26], sg[26][26];
     __shared__ double hp[5][26][16];
     __shared__ double red[4];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
     const int VH = H - 10, VW = W - 10;
-    const float* xb = x + (size_t)b * H * W;
+    const X* xb = x + (size_t)b * H * W;
     const uint8_t* gb = gt + (size_t)b * H * W;
     for (int i = tid; i < 26 * 26; i += 256) {
         const int r = i / 26, c = i % 26;
@@ -771,9 +785,25 @@ __global__ __launch_bounds__(256) void k_ssim(const float* x, const uint8_t* gt,
     if (tid == 0) partial[(size_t)b * tiles_x * tiles_y + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-hipError_t launch_ssim(hipStream_t s, const float* x, const uint8_t* gt, double* partial, int B, int H, int W) {
+template <typename X>
+hipError_t launch_ssim(hipStream_t s, const X* x, const uint8_t* gt, double* partial, int B, int H, int W) {
     const int tx = (W - 10 + 15) / 16, ty = (H - 10 + 15) / 16;
-    hipLaunchKernelGGL(k_ssim, dim3(tx * ty, B), dim3(256), 0, s, x, gt, partial, H, W, tx, ty);
+    hipLaunchKernelGGL(k_ssim<X>, dim3(tx * ty, B), dim3(256), 0, s, x, gt, partial, H, W, tx, ty);
+    return hipGetLastError();
+}
+template hipError_t launch_ssim<float>(hipStream_t, const float*, const uint8_t*, double*, int, int, int);
+template hipError_t launch_ssim<double>(hipStream_t, const double*, const uint8_t*, double*, int, int, int);
+
+// float -> double widening of the image handed to the double-precision synthesis (exact)
+__global__ __launch_bounds__(256) void k_widen(const float4* in, double4* out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        out[i] = make_double4((double)v.x, (double)v.y, (double)v.z, (double)v.w);
+    }
+}
+hipError_t launch_widen(hipStream_t s, const float* in, double* out, size_t n) {
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(k_widen, dim3(pw_grid(n4)), dim3(256), 0, s, (const float4*)in, (double4*)out, n4);
     return hipGetLastError();
 }
 

@@ -862,15 +862,15 @@ void slice256_destroy(Slice256* f) {
     delete f;
 }
 
-Slice256* slice256_create(int Bmax, hipError_t* err) {
+Slice256* slice256_create(int Bmax, int pad_kb, int yh_pad_kb, hipError_t* err) {
     Slice256* f = new Slice256();
     f->Bmax = Bmax;
     // 4 KiB of padding behind every slice of the state and of the table: with 256 KiB strides the streams of all resident
     // workgroups sit on the same address bits above bit 17 at the same time; +2.4 % at the driver's 20 steps (9740 -> 9977 it/s,
     // five alternating runs, variants_r03.log v28), +-0 at 100.  0 = round 3's in-place, unpadded form.
-    auto env_kb = [](const char* name, int dflt) { const char* ev = getenv(name); const int v = ev ? atoi(ev) : dflt; return v > 0 ? v : 0; };
-    f->pad = env_kb("PNP_SLICE_PAD_KB", 4) * 256;             // floats
-    f->yh_pad = env_kb("PNP_SLICE_YH_PAD_KB", 4) * 128;       // complex elements
+    // (PNP_SLICE_PAD_KB / PNP_SLICE_YH_PAD_KB, read and range-checked at pnp_ctx_create)
+    f->pad = (pad_kb > 0 ? pad_kb : 0) * 256;                 // floats
+    f->yh_pad = (yh_pad_kb > 0 ? yh_pad_kb : 0) * 128;        // complex elements
     hipError_t e = hipMalloc((void**)&f->Yh, (size_t)Bmax * (YH3_SLICE + f->yh_pad) * sizeof(c32));
     if (e == hipSuccess && f->pad > 0) e = hipMalloc((void**)&f->zs, (size_t)Bmax * (65536 + f->pad) * sizeof(float));
     if (e == hipSuccess && f->pad > 0) e = hipMalloc((void**)&f->ws, (size_t)Bmax * (65536 + f->pad) * sizeof(float));
@@ -917,7 +917,7 @@ static hipError_t launch_slice(hipStream_t s, const SliceArgs& a, int prox) {
     return hipGetLastError();
 }
 
-// Experiment knobs (PNP_SLICE_QUEUES, PNP_SLICE_SEGMENT; default: ONE launch): a run can be cut into parts of the
+// Experiment knobs (FusedSchedule::slice_queues / slice_segment; default: ONE launch): a run can be cut into parts of the
 // batch on several HIP queues times consecutive launches of a part of the iterations.  Workgroups differ in speed
 // by +-10 % (up to +25 %) and with two workgroups per compute unit the slowest unit sets the time of a single
 // launch (makespan 8.0 ms against 7.0 ms of balanced work at 50 iterations); smaller units were meant to even this
@@ -934,11 +934,10 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     a.prof = nullptr;
     a.slice_xor = 0;
     a.flip = 0;
-    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    a.slice_xor = env_int("PNP_SLICE_XOR", 0);
+    a.slice_xor = sch.slice_xor;
     if (a.slice_xor < 0 || (B & (B - 1)) != 0 || a.slice_xor >= B) a.slice_xor = 0;      // a permutation only for power-of-two batches
     const int prox = cnc ? 2 : (sch.l1_two_state ? 1 : 3);
-    int queues = env_int("PNP_SLICE_QUEUES", 1), seg_len = env_int("PNP_SLICE_SEGMENT", 0);   // measured: 1 launch is best
+    int queues = sch.slice_queues, seg_len = sch.slice_segment;                                // measured: 1 launch is best
     if (queues < 1) queues = 1;
     if (queues > Slice256::MAXQ) queues = Slice256::MAXQ;
     if (B < 64 * queues) queues = 1;
@@ -962,7 +961,7 @@ hipError_t slice256_run(Slice256* f, hipStream_t s, float* z, float* w, float* x
     // A batch larger than the chip runs in rounds (one slice per compute unit at a time), and the slices of the LAST round
     // are the ones the Infinity Cache still holds when the call returns: every other call walks the batch backwards, so that
     // a following call starts on warm data (DESIGN.md 4.1, round hand-over).  Slices are independent: results do not change.
-    if (!prof_path && B > slice256_cus(f) && env_int("PNP_SLICE_FLIP", 1)) { a.flip = f->flip; f->flip ^= 1; }
+    if (!prof_path && B > slice256_cus(f) && sch.slice_flip) { a.flip = f->flip; f->flip ^= 1; }
     hipError_t e = hipSuccess;
     if (queues > 1) {
         if (!f->ev_fork) e = hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming);

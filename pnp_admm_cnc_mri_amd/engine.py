@@ -31,8 +31,9 @@ class Engine:
     """One context per (device, H, W, Bmax).  Not thread-safe, not re-entrant (as the ABI says)."""
 
     def __init__(self, H=256, W=256, Bmax=1, device=0, precision='f32'):
-        """precision='f64' makes an fp64 validation context (generic kernels in double; only
-        upload / init_state / set_state / get_state / admm_l1 / admm_cnc / x are available)."""
+        """precision='f64': the reference's own arithmetic (S4:109) -- every buffer and step in double; problem
+        (upload / synthesize), state, whole loops, x, metrics and SSIM are available, the step-wise
+        float32 operators of the PnP path are not (pnp_mri.h, "double-precision context")."""
         if precision not in ('f32', 'f64'):
             raise ValueError("precision must be 'f32' or 'f64'")
         self._L = _lib.lib()
@@ -139,24 +140,31 @@ class Engine:
         img = np.asarray(img)
         if img.ndim == 2:
             img = img[None]
-        img = _host(img, np.float32)
+        img = _host(img, np.float32)                      # the reference's img_L is float32 in either precision
         B = img.shape[0]
-        noise = _host(noise, np.complex64)
+        noise = _host(noise, self._cplx)
         per = 1 if noise.ndim == 3 else 0
         if per and noise.shape[0] != B:
             raise ValueError('noise batch does not match images')
+        if noise.shape[-2:] != (self.H, self.W):
+            raise ValueError('noise shape %s does not match engine %dx%d' % (noise.shape[-2:], self.H, self.W))
         bank, mid = self._masks(masks, mask_id, B)
-        _lib.check(self._L.pnp_synthesize_problem(self._ctx, _ptr(img), _ptr(noise), per, _ptr(bank), _ptr(mid),
-                                                  B, bank.shape[0], 0))
+        fn = self._L.pnp_synthesize_problem_f64 if self.f64 else self._L.pnp_synthesize_problem
+        _lib.check(fn(self._ctx, _ptr(img), _ptr(noise), per, _ptr(bank), _ptr(mid), B, bank.shape[0], 0))
         self.B = B
 
     def download_y(self):
-        y = np.empty((self.B, self.H, self.W), np.complex64)
-        _lib.check(self._L.pnp_download_y(self._ctx, _ptr(y), 0))
+        y = np.empty((self.B, self.H, self.W), self._cplx)
+        fn = self._L.pnp_download_y_f64 if self.f64 else self._L.pnp_download_y
+        _lib.check(fn(self._ctx, _ptr(y), 0))
         return y
 
     def init_state(self):
         _lib.check(self._L.pnp_init_state(self._ctx))
+
+    def prepare_loops(self):
+        """Build now the per-problem tables the whole loops will use (otherwise built by the first loop call)."""
+        _lib.check(self._L.pnp_prepare_loops(self._ctx))
 
     def set_state(self, z=None, w=None):
         zz = None if z is None else (z if _is_dev(z) else _host(z, self._real))
@@ -237,13 +245,15 @@ class Engine:
         gt = _host(gt_u8, np.uint8)
         psnr = np.empty(self.B, np.float64)
         re = np.empty(self.B, np.float64)
-        _lib.check(self._L.pnp_metrics(self._ctx, _ptr(x_dev), _ptr(gt), 0,
-                                       psnr.ctypes.data_as(_lib.c_double_p), re.ctypes.data_as(_lib.c_double_p)))
+        fn = self._L.pnp_metrics_f64 if self.f64 else self._L.pnp_metrics
+        _lib.check(fn(self._ctx, _ptr(x_dev), _ptr(gt), 0,
+                      psnr.ctypes.data_as(_lib.c_double_p), re.ctypes.data_as(_lib.c_double_p)))
         return psnr, re
 
     def ssim(self, x_dev, gt_u8):
         """-> ssim[B] of img_E = x*255 against uint8 ground truth (utils/utils_image.py:570-615), on device."""
         gt = _host(gt_u8, np.uint8)
         out = np.empty(self.B, np.float64)
-        _lib.check(self._L.pnp_ssim(self._ctx, _ptr(x_dev), _ptr(gt), 0, out.ctypes.data_as(_lib.c_double_p)))
+        fn = self._L.pnp_ssim_f64 if self.f64 else self._L.pnp_ssim
+        _lib.check(fn(self._ctx, _ptr(x_dev), _ptr(gt), 0, out.ctypes.data_as(_lib.c_double_p)))
         return out

@@ -28,8 +28,12 @@ def shard_sizes(B, world):
 
 def gather_slices(x_local, B_total, dst=0, group=None):
     """x_local: torch tensor [b_r, H, W] of this rank (device tensor for nccl, CPU for gloo).
-    Returns the [B_total, H, W] tensor on `dst` (None elsewhere).  Uneven shards are padded to
-    the largest shard for the collective and trimmed on the root."""
+    Returns the [B_total, H, W] tensor on `dst` (None elsewhere).
+
+    The root receives into ONE [world * bmax, H, W] tensor whose per-rank views are the gather
+    list, so even shards (the benchmark's and every power-of-two job's case) need no second copy
+    of the result: the tensor returned IS the receive buffer.  Uneven shards are padded to the
+    largest shard for the collective and compacted on the root."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -45,10 +49,15 @@ def gather_slices(x_local, B_total, dst=0, group=None):
         pad = torch.zeros((bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         pad[:send.shape[0]] = send
         send = pad
-    bufs = [torch.empty_like(send) for _ in range(world)] if is_dst else None
+    recv, bufs = None, None
+    if is_dst:
+        recv = torch.empty((world * bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        bufs = [recv[r * bmax:(r + 1) * bmax] for r in range(world)]     # contiguous views: the collective fills `recv` in place
     dist.gather(send, bufs, dst=dst, group=group)
     if not is_dst:
         return None
+    if all(n == bmax for n in sizes):
+        return recv
     return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
 
 
@@ -69,8 +78,9 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
     `functools.partial` when it takes leading model names) on this rank's contiguous block of slices
     and gather the reconstructions on `dst`.
 
-    Every rank passes the SAME full `images` / `y` / `mask_id`; returns a float32 array
-    [B_total, H, W] on `dst`, None elsewhere.  With no process group it is a plain call.
+    Every rank passes the SAME full `images` / `y` / `mask_id`; returns an array [B_total, H, W] on `dst`
+    (float32; float64 when the solver is run with precision='f64'), None elsewhere.  With no process
+    group it is a plain call.
     gather_device: torch device for the collective (default: cuda:<local device> under nccl, cpu under gloo).
     """
     import torch
@@ -85,6 +95,7 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
         world = dist.get_world_size(group)
         lo, hi = shard_range(B_total, world, dist.get_rank(group))
     kw = dict(solver_kwargs)
+    real = np.float64 if kw.get('precision') == 'f64' else np.float32
     if images is not None:
         kw['images'] = np.asarray(images)[lo:hi]
     if y is not None:
@@ -96,10 +107,10 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
     if hi > lo:
         res = solver(mask, noises, **kw)
         out = res[0] if isinstance(res, tuple) else res
-        x_local = np.stack([np.asarray(out[n], dtype=np.float32) for n in range(hi - lo)])
+        x_local = np.stack([np.asarray(out[n], dtype=real) for n in range(hi - lo)])
     else:
         m = np.asarray(mask)
-        x_local = np.zeros((0,) + m.shape[-2:], np.float32)
+        x_local = np.zeros((0,) + m.shape[-2:], real)
     if world == 1:
         return x_local
     if gather_device is None:

@@ -13,6 +13,9 @@ bypass the file system through the extra keyword arguments
     y=        [B,H,W] complex measurements (skips the synthesis  y = fft2(img)*mask + noises)
     mask_id=  [B] index into `mask` when `mask` is a bank [K,H,W]            (build extension)
     testsets=, testset_name=, results=, save_E=, device=, return_info=
+    precision= 'f32' (default: float32 / complex64 device arithmetic, the throughput path) or 'f64' (the reference's own
+               float64 arithmetic, S4:109: every buffer and step in double -- the setting that meets 1e-5 relative L2 on the
+               committed 50-iteration CNC presets and beyond)
 
 The PnP entry points (PNP_ADMM_L1_D, PNP_ADMM_CNC_D, PNP_ADMM_CNC_DnCNN) live in solvers_pnp.py.
 """
@@ -61,9 +64,12 @@ class _Job:
 
     def __init__(self, mask, noises, tag, suffix, images=None, y=None, mask_id=None, testsets='testsets',
                  testset_name='Set1', results='results', save_E=None, device=0, log=None, ssim=None,
-                 psnr_fmt='{:.4f}'):
+                 psnr_fmt='{:.4f}', precision='f32'):
         # psnr_fmt: S1:150 and S3:320 print the per-image PSNR with two decimals, S4:155 / S6:332 / S6:548 with four
         self.tag, self.suffix, self.psnr_fmt = tag, suffix, psnr_fmt
+        if precision not in ('f32', 'f64'):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.precision = precision
         mask = np.asarray(mask)
         self.mask_bank = mask[None] if mask.ndim == 2 else mask
         self.H, self.W = self.mask_bank.shape[1:]
@@ -113,7 +119,7 @@ class _Job:
     def open_engine(self, stream=None):
         """stream: HIP stream handle every engine call is ordered on (PnP: torch's current stream),
         set BEFORE the first kernel so upload / synthesis / init and the loop share one queue."""
-        eng = Engine(self.H, self.W, Bmax=self.B, device=self.device)
+        eng = Engine(self.H, self.W, Bmax=self.B, device=self.device, precision=self.precision)
         if stream is not None:
             eng.set_stream(stream)
         if self.y is not None:
@@ -156,13 +162,13 @@ class _Job:
 
 
 def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets', testset_name='Set1',
-            results='results', save_E=None, device=0, return_info=False, **ADMM_L1_opts):
+            results='results', save_E=None, device=0, return_info=False, precision='f32', **ADMM_L1_opts):
     """ADMM with L1 prox on the MI355X engine.  Reference: "【1】ADMM_L1.py":29-169."""
     iter_num = ADMM_L1_opts.get('iter_num', 20)          # S1:35
     lambda1 = ADMM_L1_opts.get('lambda1', 0.04)          # S1:36
     reo = ADMM_L1_opts.get('reo', 0.04)                  # S1:37
     job = _Job(mask, noises, 'ADMM_L1', '_PDG L1', images, y, mask_id, testsets, testset_name, results, save_E, device,
-               psnr_fmt='{:.2f}')                        # S1:150
+               psnr_fmt='{:.2f}', precision=precision)   # S1:150
     with job.open_engine() as eng:
         eng.admm_l1(iter_num, lambda1, reo)              # S1:111-126, all slices, on device
         x = eng.x()                                      # iter_num = 0: the initial x = |ifft2(y)| (S4:103, 138)
@@ -171,14 +177,15 @@ def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets'
 
 
 def ADMM_CNC(mask, noises, images=None, y=None, mask_id=None, testsets='testsets', testset_name='Set1',
-             results='results', save_E=None, device=0, return_info=False, **ADMM_CNC_opts):
+             results='results', save_E=None, device=0, return_info=False, precision='f32', **ADMM_CNC_opts):
     """ADMM with the convex-non-convex z-step.  Reference: "【4】ADMM_CNC .py":31-174."""
     iter_num = ADMM_CNC_opts.get('iter_num', 4)          # S4:37
     alpha = ADMM_CNC_opts.get('alpha', 0.4)              # S4:38
     lambda1 = ADMM_CNC_opts.get('lambda1', 0.04)         # S4:39
     reo = ADMM_CNC_opts.get('reo', 2.75)                 # S4:40  (reo is 1/beta of the paper)
     b = ADMM_CNC_opts.get('b', 1)                        # S4:41  (b is b^2 of the paper)
-    job = _Job(mask, noises, 'ADMM_CNC', '_ADMM CNC', images, y, mask_id, testsets, testset_name, results, save_E, device)
+    job = _Job(mask, noises, 'ADMM_CNC', '_ADMM CNC', images, y, mask_id, testsets, testset_name, results, save_E, device,
+               precision=precision)
     with job.open_engine() as eng:
         eng.admm_cnc(iter_num, alpha, lambda1, reo, b)   # S4:115-132
         x = eng.x()                                      # iter_num = 0: the initial x = |ifft2(y)| (S4:103, 138)

@@ -8,6 +8,10 @@
 #   commit (build container: needs .git): the library of an earlier commit:   bash profiles/variants.sh commit <sha> <name>
 #   run   (on the GPU box):                              bash profiles/variants.sh run "<bench args>" <reps> <name> [<name> ...]
 #          "base" names the in-tree library.  Prints value (it/s) per arm and repetition.
+#   knobs (here or on the box): the whole library with -DPNP_EXPERIMENT_KNOBS (PNP_SLICE_XOR / _QUEUES / _SEGMENT / _FLIP,
+#          PNP_F512_QUEUES / PNP_F256S_QUEUES, PNP_GENERIC_STOCKHAM are compiled OUT of the product library since round 4):
+#          bash profiles/variants.sh knobs   ->  build/variants/lib_knobs.so, then e.g.
+#          PNP_MRI_LIB=build/variants/lib_knobs.so bash profiles/ab_env.sh "--steps 20 --warmup 5" 3 PNP_SLICE_FLIP 0 1
 #   prof  (on the GPU box): phase clocks of the slice kernel at batch 64 and 512:  bash profiles/variants.sh prof <name> ...
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -26,6 +30,17 @@ build)
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib_$NAME.so $OBJS -ldl
   echo "built $V/lib_$NAME.so [$FLAGS]"
+  ;;
+knobs)
+  mkdir -p $V/knobs
+  OBJS=""
+  for o in api kernels_generic kernels_fused256 kernels_fused512 kernels_slice256; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off -DPNP_EXPERIMENT_KNOBS $2 -c $C/$o.hip -o $V/knobs/$o.o &
+    OBJS="$OBJS $V/knobs/$o.o"
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib_knobs.so $OBJS -ldl
+  echo "built $V/lib_knobs.so [-DPNP_EXPERIMENT_KNOBS $2]"
   ;;
 commit)
   SHA=$2; NAME=$3

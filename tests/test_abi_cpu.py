@@ -46,6 +46,31 @@ def test_argument_errors_are_codes_not_crashes():
         _lib.check(L.pnp_sync(None))
 
 
+def test_environment_knobs_are_validated_at_context_creation(monkeypatch):
+    """A mistyped or out-of-range knob fails pnp_ctx_create with PNP_E_ARG and names the variable (checked before any
+    HIP call, so this runs without a GPU); the experiment knobs of the profiling scripts are compiled out of the
+    product library and therefore ignored."""
+    L = _lib.lib()
+    ctx = _lib.ctx_p()
+    for name, bad in (('PNP_SLICE', '2'), ('PNP_SLICE', 'yes'), ('PNP_SLICE_MIN_B', '0'), ('PNP_SLICE_PAD_KB', '-1'),
+                      ('PNP_SLICE_YH_PAD_KB', '4k'), ('PNP_FUSED_STREAMS', '9'), ('PNP_FUSED_COLS', '3'), ('PNP_FUSED_CHUNK', '')):
+        monkeypatch.setenv(name, bad)
+        assert L.pnp_ctx_create(0, 256, 256, 1, C.byref(ctx)) == -1, (name, bad)
+        assert name.encode() in L.pnp_last_error()
+        monkeypatch.delenv(name)
+    # experiment knob with a value that an experiment build would reject: the product library never reads it
+    monkeypatch.setenv('PNP_SLICE_QUEUES', 'many')
+    rc = L.pnp_ctx_create(0, 256, 256, 1, C.byref(ctx))
+    assert rc in (0, -2)                                     # created on a GPU box, HIP error without a device -- never PNP_E_ARG
+    if rc == 0:
+        L.pnp_ctx_destroy(ctx)
+    import subprocess
+    syms = subprocess.check_output(['strings', _lib.LIB_PATH]).decode()
+    for knob in ('PNP_SLICE_XOR', 'PNP_SLICE_SEGMENT', 'PNP_SLICE_QUEUES', 'PNP_SLICE_FLIP', 'PNP_F512_QUEUES', 'PNP_F256S_QUEUES',
+                 'PNP_GENERIC_STOCKHAM', 'PNP_SLICE_PROF'):
+        assert knob not in syms, knob
+
+
 def test_no_cpu_fallback_when_library_is_missing(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, '_lib', None)
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libpnpmri.so'))

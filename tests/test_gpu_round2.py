@@ -38,7 +38,7 @@ def test_bench_launches_its_own_ranks():
     JSON line and exits 0.  The N = 1 invocation keeps its shape."""
     env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse-gloo', '--batch', '32', '--steps', '3',
-           '--warmup', '1']
+           '--warmup', '1', '--sustain-s', '0.2']
     r = subprocess.run(cmd, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
@@ -46,12 +46,17 @@ def test_bench_launches_its_own_ranks():
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == 'weak' and j['x_finite']
     assert j['gather_ms'] is not None and j['cpu_baseline'] is None
+    # every rank's own clocks are in the line (a slow GPU of an 8-GPU job must be visible); the job's time is their MAX
+    assert len(j['per_rank']['ms_per_step']) == 2 and abs(max(j['per_rank']['ms_per_step']) - j['ms_per_step']) <= 1e-9
+    assert len(j['per_rank']['sustained_ms_per_step']) == 2 and j['sustained']['value'] > 0
+    assert abs(max(j['per_rank']['sustained_ms_per_step']) - j['sustained']['ms_per_step']) <= 1e-9
     assert j['value'] > 0 and abs(j['value'] - 2 * 3 / (j['ms_per_step'] * 3e-3) * 32 / 512) <= 1e-6 * j['value']
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '32', '--steps', '3', '--warmup', '1',
-                         '--no-cpu-baseline'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                         '--no-cpu-baseline', '--sustain-s', '0'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r1.returncode == 0, r1.stderr.decode()[-2000:]
     j1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith('{')][0])
     assert j1['n_gpus'] == 1 and j1['gather_ms'] is None and set(j1['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert j1['sustained'] is None and j1['per_rank'] is None
     # same slices on rank 0 of both runs: the N = 2 job's rank 0 did exactly the N = 1 job's work
     assert j1['x_checksum'] == j['x_checksum']
 
@@ -454,7 +459,8 @@ def test_bench_runs_its_collectives_on_rccl_with_one_rank():
     with socket.socket() as so:
         so.bind(('127.0.0.1', 0))
         port = so.getsockname()[1]
-    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '64', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '64', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+            '--sustain-s', '0.2']
     r = subprocess.run(base, env=dict(env_, PNP_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -462,7 +468,7 @@ def test_bench_runs_its_collectives_on_rccl_with_one_rank():
     assert len(r.stdout.decode().strip().splitlines()) == 1, r.stdout.decode()[:400]
     j = json.loads(r.stdout.decode().strip())
     assert j['n_gpus'] == 1 and j['gather_ms'] is not None and j['gather_ms'] > 0 and j['x_finite']
-    assert j['config']['path'] == 'slice'
+    assert j['config']['path'] == 'slice' and len(j['per_rank']['ms_per_step']) == 1
     r1 = subprocess.run(base, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r1.returncode == 0, r1.stderr.decode()[-3000:]
     j1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith('{')][0])
@@ -474,13 +480,22 @@ def test_bench_line_carries_parity_and_the_f64_record():
     W + K iterations) and times the double-precision engine in the same process."""
     env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '64', '--steps', '8', '--warmup', '2',
-                        '--cpu-budget', '1'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        '--cpu-budget', '1', '--sustain-s', '0.5'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
     assert j['parity']['iterations'] == 10 and len(j['parity']['rel_l2_vs_oracle']) == 3
     assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5
     assert j['f64']['dtype'] == 'f64' and j['f64']['value'] > 0 and max(j['f64']['rel_l2_vs_oracle']) <= 1e-9
     assert j['cpu_baseline']['cores'] == 1 and j['roofline']['traffic_measured_in_this_run'] is False
+    # roofline.frac is a PHYSICAL fraction (bytes the kernels move / time / peak), the 57 N contract figure sits beside it
+    rf = j['roofline']
+    assert 0 < rf['frac'] <= 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) <= 1e-12
+    assert rf['bytes_from'] in ('pmc', 'own_algorithmic') and rf['frac_contract_57N'] > rf['frac']
+    assert rf['own_algorithmic_bytes_per_iteration'] == 20.0 * 65536 * 64 and rf['contract_bytes_per_iteration'] == 57.0 * 65536 * 64
+    # the sustained record: >= 0.5 s of back-to-back calls after a pre-heat, same workload; x / parity above are those of W + K iterations
+    su = j['sustained']
+    assert su['span_s'] >= 0.3 and su['steps'] % 8 == 0 and su['value'] > 0 and 0 < su['frac'] <= 1
+    assert 0.5 * j['value'] <= su['value'] <= 1.2 * j['value']
 
 
 def test_bench_pnp_line_and_its_two_rank_launch():
@@ -510,7 +525,7 @@ def test_bench_line_at_512_with_its_cpu_legs():
     comparison and both CPU baselines run on 512 x 512 data (they once built 256 x 256 phantoms for a 512 x 512 mask)."""
     env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '512', '--batch', '8', '--steps', '2', '--warmup', '1',
-                        '--cpu-budget', '0.5'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        '--cpu-budget', '0.5', '--sustain-s', '0.2'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     j = json.loads(r.stdout.decode().strip())
     assert '512x512' in j['metric'] and j['config']['path'] == 'fused' and j['f64'] is None
