@@ -63,7 +63,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('PNP_BENCH_FORCE_DIST') == '1':       # the env hook exercises RCCL with one rank (as in bench.py)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.rehearse_gloo:
@@ -143,9 +143,11 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         assert (x_all is not None) == (rank == 0)
-        tt = torch.tensor([wall, t_dc, t_cnn, gather_ms], dtype=torch.float64, device='cpu' if args.rehearse_gloo else 'cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, t_dc, t_cnn, gather_ms = (float(v) for v in tt.cpu())
+        mine = torch.tensor([wall, t_dc, t_cnn, gather_ms], dtype=torch.float64, device='cpu' if args.rehearse_gloo else 'cuda')
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                    # every rank's own clocks: a slow GPU shows in the line
+        per_rank = torch.stack(every).cpu()
+        wall, t_dc, t_cnn, gather_ms = (float(v) for v in per_rank.max(dim=0).values)   # the job's time: MAX over ranks
     if rank == 0:
         K = args.steps
         dc_ms, cnn_ms = t_dc / K, t_cnn / K
@@ -161,6 +163,8 @@ def main():
                                    % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
                        'cnn_batch': args.cnn_batch},
             'slice_iterations_per_s': world * K * B / wall, 'gather_ms': gather_ms,
+            'per_rank': None if dist is None else {'ms_per_step': [float(v) / K * 1e3 for v in per_rank[:, 0]],
+                                                   'gather_ms': [float(v) for v in per_rank[:, 3]]},
             'fft_prox': {'ms_per_step': dc_ms, 'share': dc_ms / (dc_ms + cnn_ms), 'algorithmic_bytes': alg_bytes,
                          'roofline': {'bound': 'hbm', 'achieved': alg_bytes / (dc_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                       'frac': alg_bytes / (dc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -586,31 +586,73 @@ struct FCol2Args {
     R c;
 };
 
+// One block per (tile of 8 columns k2 = 8 m + kl, slice pair); tile 16 = the self-mirrored columns k2 = 0 and 128.  As in
+// k_fprepare each slice's y / mask tile and its mirror image (rows -k1, columns -k2) go through LDS: global memory is read in
+// row segments of 8 complex values (64 bytes in float, 128 in double) instead of one element per 2 KiB (4 KiB) row, and the
+// table is written in its own order.  (Until round 4 a block held ONE column: 256 threads x 2 KiB stride, the line fetched for
+// every element.)  Arithmetic = hermitian_entry_t (fused_layout.h): unsampled entries are selected away, never multiplied.
+constexpr int FP2_P = 9;
 template <typename R>
 __global__ __launch_bounds__(256) void k_fprepare2(const cxT<R>* y, const uint8_t* mask_bank, const int32_t* mask_id,
                                                    cxT<R>* Yh, uint32_t* Mh, int B) {
-    __shared__ int nib[256];
-    const int tid = threadIdx.x, j = tid >> 4, t = tid & 15;
-    const int k2 = blockIdx.x, pair = blockIdx.y, k1 = t + 16 * j;
-    int code[2] = {0, 0};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int sl = 2 * pair + s;
-        cxT<R> yh = mk<R>((R)0, (R)0);
+    using C = cxT<R>;
+    __shared__ C yd[256 * FP2_P], ym[256 * FP2_P];               // direct tile [row][kl], mirror tile [row][kl] = y[row][-k2]
+    __shared__ uint8_t md[256 * FP2_P], mm[256 * FP2_P];
+    __shared__ uint8_t nib[256 * 8];                             // [k1][kl]: code of slice a | code of slice b << 2
+    const int tid = threadIdx.x, m = blockIdx.x, pair = blockIdx.y;
+    const bool self = (m == F2_TILES - 1);
+    const int ncol = self ? 2 : 8;
+    auto col_of = [&](int kl) { return self ? (kl ? 128 : 0) : 8 * m + kl; };
+    for (int e = tid; e < 256 * 8; e += 256) nib[e] = 0;
+#pragma unroll 1
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int sl = 2 * pair + sidx;
+        __syncthreads();
         if (sl < B) {
             const int mid = mask_id ? mask_id[sl] : 0;
-            hermitian_entry_t<R>(y + (size_t)sl * 65536, mask_bank + (size_t)mid * 65536, k1, k2, yh, code[s]);
+            const C* ys = y + (size_t)sl * 65536;
+            const uint8_t* ms = mask_bank + (size_t)mid * 65536;
+#pragma unroll 4
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 3, c = idx & 7;
+                if (c < ncol) {
+                    const int k2 = col_of(c), k2m = (256 - k2) & 255;
+                    yd[r * FP2_P + c] = ys[r * 256 + k2];
+                    md[r * FP2_P + c] = ms[r * 256 + k2];
+                    ym[r * FP2_P + c] = ys[r * 256 + k2m];
+                    mm[r * FP2_P + c] = ms[r * 256 + k2m];
+                }
+            }
         }
-        Yh[yh2_index(pair, k2, j, t, s)] = yh;
-    }
-    nib[tid] = code[0] | (code[1] << 2);
-    __syncthreads();
-    if (tid < 32) {
-        const int tt = tid & 15, s = tid >> 4;
-        uint32_t v = 0;
+        __syncthreads();
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) v |= (uint32_t)((nib[jj * 16 + tt] >> (2 * s)) & 3) << (2 * jj);
-        Mh[mh2_index(pair, k2, tt, s)] = v;
+        for (int i = 0; i < 8; ++i) {
+            const int o = tid + 256 * i;                         // [wave 4][j 16][tq 4][kl 8]: the lanes of this slice, in storage order
+            const int kl = o & 7, tq = (o >> 3) & 3, j = (o >> 5) & 15, wv = o >> 9;
+            const int k1 = 4 * wv + tq + 16 * j, r2 = (256 - k1) & 255;
+            const bool valid = kl < ncol && (self || 8 * m + kl >= 1);      // k2 = 0 lives in tile 16
+            if (!valid) continue;
+            C yh = mk<R>((R)0, (R)0);
+            int code = 0;
+            if (sl < B) {
+                const int m1 = md[k1 * FP2_P + kl] != 0, m2 = mm[r2 * FP2_P + kl] != 0;
+                const C y1 = yd[k1 * FP2_P + kl], y2 = ym[r2 * FP2_P + kl];
+                yh = mk<R>((R)0.5 * ((m1 ? y1.x : (R)0) + (m2 ? y2.x : (R)0)), (R)0.5 * ((m1 ? y1.y : (R)0) - (m2 ? y2.y : (R)0)));
+                code = m1 + m2;
+            }
+            nib[k1 * 8 + kl] |= (uint8_t)(code << (2 * sidx));   // one thread per (k1, kl): no race
+            Yh[yh2_index(pair, col_of(kl), j, 4 * wv + tq, sidx)] = yh;
+        }
+    }
+    __syncthreads();
+    {
+        const int s2 = tid & 1, kl = (tid >> 1) & 7, t = tid >> 4;
+        if (kl < ncol && (self || 8 * m + kl >= 1)) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) v |= (uint32_t)((nib[(t + 16 * jj) * 8 + kl] >> (2 * s2)) & 3) << (2 * jj);
+            Mh[mh2_index(pair, col_of(kl), t, s2)] = v;
+        }
     }
 }
 
@@ -722,7 +764,7 @@ hipError_t fused256s_prepare(Fused256S<R>* f, hipStream_t s, const void* y, cons
                              const int32_t* mask_id, int B) {
     if (B > f->Bmax) return hipErrorInvalidValue;
     const int np = (B + 1) / 2;
-    hipLaunchKernelGGL(k_fprepare2<R>, dim3(F_HALF, np), dim3(256), 0, s, reinterpret_cast<const cxT<R>*>(y), mask_bank,
+    hipLaunchKernelGGL(k_fprepare2<R>, dim3(F2_TILES, np), dim3(256), 0, s, reinterpret_cast<const cxT<R>*>(y), mask_bank,
                        mask_id, f->Yh, f->Mh, B);
     return hipGetLastError();
 }

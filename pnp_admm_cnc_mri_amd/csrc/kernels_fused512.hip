@@ -53,35 +53,71 @@ __device__ __forceinline__ float dpp_row_ror8(float v) {        // lane ^ 8 insi
 }
 
 // ------------------------------------------------------------------------------------------
-// table preparation: one block per (column k2 = 0..256, pair)
+// table preparation (once per uploaded problem): one block per (tile of 8 columns k2 = 8 m + kl, slice pair); tile 32 = the
+// column k2 = 256.  Each slice's y / mask tile and its mirror image (rows -k1, columns -k2) go through LDS, so that global
+// memory is read in 64-byte row segments and the table block is written in its own contiguous order (until round 4 a block
+// held ONE column and read y with a 4 KiB stride).  Arithmetic = hermitian_entry512 (fused_layout.h).
 // ------------------------------------------------------------------------------------------
+constexpr int FP5_P = 9;
 __global__ __launch_bounds__(256) void k5_prepare(const c32* y, const uint8_t* mask_bank, const int32_t* mask_id,
                                                   float4* Yh, unsigned long long* Mh, int B) {
-    __shared__ int nib[512];                         // [t:32][q:16]
-    const int tid = threadIdx.x, k2 = blockIdx.x, pair = blockIdx.y;
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int k1 = tid + 256 * rep;
-        c32 yh[2] = {mk(0.f, 0.f), mk(0.f, 0.f)};
-        int code[2] = {0, 0};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int sl = 2 * pair + s;
-            if (sl < B) {
-                const int mid = mask_id ? mask_id[sl] : 0;
-                hermitian_entry512(y + (size_t)sl * NN5, mask_bank + (size_t)mid * NN5, k1, k2, yh[s], code[s]);
+    __shared__ c32 yd[512 * FP5_P], ym[512 * FP5_P];             // direct tile [row][kl], mirror tile [row][kl] = y[row][-k2]
+    __shared__ uint8_t md[512 * FP5_P], mm[512 * FP5_P];
+    __shared__ uint8_t nib[512 * 8];                             // [k1][kl]: code of slice a | code of slice b << 2
+    const int tid = threadIdx.x, m = blockIdx.x, pair = blockIdx.y;
+    const int ncol = (m == F5_TILES - 1) ? 1 : 8;
+    c32 ya[16];                                                  // slice a's entries of this thread's 16 output positions
+    for (int e = tid; e < 512 * 8; e += 256) nib[e] = 0;
+#pragma unroll 1
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int sl = 2 * pair + sidx;
+        __syncthreads();
+        if (sl < B) {
+            const int mid = mask_id ? mask_id[sl] : 0;
+            const c32* ys = y + (size_t)sl * NN5;
+            const uint8_t* ms = mask_bank + (size_t)mid * NN5;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 3, c = idx & 7;
+                if (c < ncol) {
+                    const int k2 = 8 * m + c, k2m = (512 - k2) & 511;
+                    yd[r * FP5_P + c] = ys[r * 512 + k2];
+                    md[r * FP5_P + c] = ms[r * 512 + k2];
+                    ym[r * FP5_P + c] = ys[r * 512 + k2m];
+                    mm[r * FP5_P + c] = ms[r * 512 + k2m];
+                }
             }
         }
-        Yh[yh5_index(pair, k2, k1)] = make_float4(yh[0].x, yh[0].y, yh[1].x, yh[1].y);
-        const int t = 2 * (k1 & 15) + (k1 >> 8), q = (k1 >> 4) & 15;
-        nib[t * 16 + q] = code[0] | (code[1] << 2);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = tid + 256 * i;                         // storage order inside the tile: [wave 4][q 16][lane 64], lane = kl + 8 (t & 7)
+            const int lane = o & 63, q = (o >> 6) & 15, wv = o >> 10;
+            const int kl = lane & 7, t = 8 * wv + (lane >> 3);
+            const int k1 = (t >> 1) + 16 * q + 256 * (t & 1), r2 = (512 - k1) & 511;       // the k-layout of fft16.h
+            c32 yh = mk(0.f, 0.f);
+            int code = 0;
+            if (sl < B && kl < ncol) {
+                const int m1 = md[k1 * FP5_P + kl] != 0, m2 = mm[r2 * FP5_P + kl] != 0;
+                const c32 y1 = yd[k1 * FP5_P + kl], y2 = ym[r2 * FP5_P + kl];
+                // select, do not multiply: an unsampled y entry (possibly NaN/Inf in user data) must not reach the result
+                yh = mk(0.5f * ((m1 ? y1.x : 0.0f) + (m2 ? y2.x : 0.0f)), 0.5f * ((m1 ? y1.y : 0.0f) - (m2 ? y2.y : 0.0f)));
+                code = m1 + m2;
+            }
+            if (kl < ncol) nib[k1 * 8 + kl] |= (uint8_t)(code << (2 * sidx));       // one thread per (k1, kl): no race
+            if (sidx == 0) ya[i] = yh;
+            else if (kl < ncol) Yh[(size_t)pair * YH5_PAIR + (size_t)m * 4096 + o] = make_float4(ya[i].x, ya[i].y, yh.x, yh.y);
+        }
     }
     __syncthreads();
-    if (tid < 32) {
-        unsigned long long v = 0;
+    {
+        const int lane = tid & 63, wv = tid >> 6, kl = lane & 7, t = 8 * wv + (lane >> 3);
+        if (kl < ncol) {
+            unsigned long long v = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v |= (unsigned long long)nib[tid * 16 + q] << (4 * q);
-        Mh[mh5_index(pair, k2, tid)] = v;
+            for (int q = 0; q < 16; ++q) v |= (unsigned long long)nib[((t >> 1) + 16 * q + 256 * (t & 1)) * 8 + kl] << (4 * q);
+            Mh[(size_t)pair * MH5_PAIR + (size_t)m * 256 + tid] = v;
+        }
     }
 }
 
@@ -324,7 +360,7 @@ hipError_t fused512_prepare(Fused512* f, hipStream_t s, const float2* y, const u
                             const int32_t* mask_id, int B) {
     if (B > f->Bmax) return hipErrorInvalidValue;
     const int np = (B + 1) / 2;
-    hipLaunchKernelGGL(k5_prepare, dim3(F5_HALF, np), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank,
+    hipLaunchKernelGGL(k5_prepare, dim3(F5_TILES, np), dim3(256), 0, s, reinterpret_cast<const c32*>(y), mask_bank,
                        mask_id, f->Yh, f->Mh, B);
     return hipGetLastError();
 }

@@ -349,10 +349,17 @@ __device__ __forceinline__ void col16_fft(c32 (&a)[16], const c32* twl, c32* col
     fft256_tail<INV>(a);
 }
 
+// The operands of the pointwise pass (measurements / noise, mask bytes) are requested at the START of the kernel, in the
+// row-major order that pass walks (coalesced 128-byte row segments), and are consumed after the forward transform: their
+// memory latency hides behind the tile load and the transform.  (Until round 4 they were fetched inside the pass, where
+// every wave of the workgroup waited a full memory latency between two barriers: k_cols16<true, 1, true> 233 us at 512
+// slices = 3.3 TB/s.)  y travels in 32 registers (3 workgroups per compute unit instead of 4); the mask tile (16 bytes per
+// row) goes through 4 KiB of LDS as four dword loads per thread instead of sixteen byte loads.
 template <bool PRE, int MID, bool POST>
-__global__ __launch_bounds__(256) void k_cols16(ColArgsT<float> p, int W) {
+__global__ __launch_bounds__(256, (MID != MID_NONE ? 3 : 4)) void k_cols16(ColArgsT<float> p, int W) {
     __shared__ __attribute__((aligned(16))) c32 tile[16 * C16_P];
     __shared__ c32 twl[16 * 17];
+    __shared__ uint32_t mtile[MID != MID_NONE ? 1024 : 1];           // [row 256][4 dwords = 16 mask bytes]
     const int tid = threadIdx.x;
     {
         const float2 wv = g_tw256[((tid >> 4) * (tid & 15)) & 255];
@@ -364,10 +371,39 @@ __global__ __launch_bounds__(256) void k_cols16(ColArgsT<float> p, int W) {
     const size_t sbase = (size_t)b * 256 * W;
     const c32* in = reinterpret_cast<const c32*>(p.in);
     c32* out = reinterpret_cast<c32*>(p.out);
+    c32 tin[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
-        tile[c * C16_P + r] = in[sbase + (size_t)r * W + k0 + c];
+        tin[i] = in[sbase + (size_t)r * W + k0 + c];
+    }
+    uint32_t mq[4];
+    c32 yv[16];
+    if (MID != MID_NONE) {
+        const int mid = p.mask_id ? p.mask_id[b] : 0;
+        const uint32_t* mask4 = reinterpret_cast<const uint32_t*>(p.mask_bank + (size_t)mid * 256 * W + k0);   // k0 % 16 == 0: aligned
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = tid + 256 * u;                                      // row d >> 2, columns 4 (d & 3) .. + 3 of the tile
+            mq[u] = mask4[(size_t)(d >> 2) * (W / 4) + (d & 3)];
+        }
+        if (MID != MID_MASK) {
+            const c32* yb = reinterpret_cast<const c32*>(p.y) + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 4, cc = idx & 15;
+                yv[i] = yb[(size_t)r * W + k0 + cc];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
+        tile[c * C16_P + r] = tin[i];
+    }
+    if (MID != MID_NONE) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mtile[tid + 256 * u] = mq[u];
     }
     __syncthreads();
     const int c = tid >> 4, t = tid & 15;
@@ -380,24 +416,22 @@ __global__ __launch_bounds__(256) void k_cols16(ColArgsT<float> p, int W) {
         stage_sync();
 #pragma unroll
         for (int j = 0; j < 16; ++j) col[t + 16 * j] = a[j];
-        __syncthreads();                                  // the pointwise pass walks the tile row-major (coalesced y / mask reads)
-        const int mid = p.mask_id ? p.mask_id[b] : 0;
-        const uint8_t* mask = p.mask_bank + (size_t)mid * 256 * W;
-        const c32* yb = reinterpret_cast<const c32*>(p.y) + ((MID == MID_MASK_ADD && !p.y_per_slice) ? 0 : sbase);
+        __syncthreads();                                  // the pointwise pass walks the tile row-major (the order its operands were fetched in)
+        const uint8_t* mbytes = reinterpret_cast<const uint8_t*>(mtile);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int idx = tid + 256 * i, r = idx >> 4, cc = idx & 15;
-            const size_t g = (size_t)r * W + k0 + cc;
             c32 X = tile[cc * C16_P + r];
-            const bool m = mask[g] != 0;
+            const bool m = mbytes[16 * r + cc] != 0;
+            // an unsampled measurement is SELECTED away, never multiplied: a NaN there cannot reach the result
             if (MID == MID_BLEND) {
-                if (m) { const c32 yv = yb[g]; X.x = fmaf(yv.x - X.x, p.c, X.x); X.y = fmaf(yv.y - X.y, p.c, X.y); }
+                if (m) { const c32 yy = yv[i]; X.x = fmaf(yy.x - X.x, p.c, X.x); X.y = fmaf(yy.y - X.y, p.c, X.y); }
             } else if (MID == MID_MASK) {
                 if (!m) X = mk<float>(0.f, 0.f);
             } else if (MID == MID_RESID) {
-                if (m) { const c32 yv = yb[g]; X.x -= yv.x; X.y -= yv.y; } else X = mk<float>(0.f, 0.f);
+                if (m) { const c32 yy = yv[i]; X.x -= yy.x; X.y -= yy.y; } else X = mk<float>(0.f, 0.f);
             } else if (MID == MID_MASK_ADD) {
-                const c32 nv = yb[g];
+                const c32 nv = yv[i];
                 X = m ? X + nv : nv;
             }
             tile[cc * C16_P + r] = X;

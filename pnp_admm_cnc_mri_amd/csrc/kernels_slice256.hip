@@ -144,6 +144,8 @@ __device__ __forceinline__ void ld4(bufrsrc r, int voff, int soff, float (&v)[4]
 // states.  hipcc inserts them only when soffset is NOT an SGPR (the rule of older ISAs); with an SGPR soffset
 // it let "buffer_store_dwordx4 v[28:31] ...; v_mov_b32 v28, ..." through, and on gfx950 the store then
 // wrote the NEW v28 for the last 4 lanes of each 16 -- seen as sporadic wrong z values.
+// The BUILD enforces it: `make` compiles every translation unit to assembly and tools/isa_scan.py fails it when any wide
+// buffer store with an SGPR soffset has its data registers overwritten inside the hazard window (csrc/Makefile, `check`).
 __device__ __forceinline__ void st4(bufrsrc r, int voff, int soff, const float (&v)[4]) {
     u32x4 q;
     q.x = __float_as_uint(v[0]); q.y = __float_as_uint(v[1]); q.z = __float_as_uint(v[2]); q.w = __float_as_uint(v[3]);

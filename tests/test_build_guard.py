@@ -27,6 +27,12 @@ HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'api.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off']     # = csrc/Makefile CXXFLAGS
 
+import importlib.util
+_spec = importlib.util.spec_from_file_location('isa_scan', os.path.join(CSRC, 'tools', 'isa_scan.py'))
+isa_scan = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(isa_scan)          # the scanner the Makefile runs on every build (`make check`)
+kernels_of, store_hazards = isa_scan.kernels_of, isa_scan.store_hazards
+
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
 
 
@@ -46,35 +52,6 @@ def asm(tmp_path_factory):
         outs = list(ex.map(_compile, jobs))
     return {s: open(o).read() for s, o in zip(SOURCES, outs)}
 
-
-def kernels_of(text):
-    """{mangled kernel name: {'body': [instruction lines], 'info': {key: int}}} of one assembly file."""
-    res = {}
-    lines = text.splitlines()
-    i = 0
-    while i < len(lines):
-        m = re.match(r'^(_Z\w+):\s*(;.*)?$', lines[i])
-        if not m:
-            i += 1
-            continue
-        name, body = m.group(1), []
-        i += 1
-        while i < len(lines) and not lines[i].startswith('.Lfunc_end'):
-            ln = lines[i].strip()
-            if ln and not ln.startswith((';', '.')) and not ln.endswith(':'):
-                body.append(ln.split(';')[0].strip())
-            i += 1
-        info = {}
-        while i < len(lines) and not re.match(r'^_Z\w+:', lines[i]):
-            mm = re.match(r'^; (codeLenInByte|NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|TotalNumSgprs)\s*[:=]\s*(\d+)', lines[i])
-            if mm:
-                info[mm.group(1)] = int(mm.group(2))
-            if lines[i].startswith('; COMPUTE_PGM_RSRC2:TGID_Z_EN'):
-                break
-            i += 1
-        if 'codeLenInByte' in info:
-            res[name] = {'body': body, 'info': info}
-    return res
 
 
 def test_slice_resident_kernel_stays_off_the_cliff(asm):
@@ -121,46 +98,7 @@ def test_512_column_kernel_register_budget(asm):
         assert k['info']['ScratchSize'] == 0 and k['info']['NumVgprs'] <= 168, (name, k['info'])
 
 
-def _regs(tok):
-    """VGPR numbers named by an operand token: 'v12' -> {12}, 'v[4:7]' -> {4,5,6,7}, anything else -> {}"""
-    m = re.fullmatch(r'v(\d+)', tok)
-    if m:
-        return {int(m.group(1))}
-    m = re.fullmatch(r'v\[(\d+):(\d+)\]', tok)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    return set()
 
-
-def _valu_dest(ins):
-    """VGPRs written by a VALU instruction (first operand of v_* except compares / readlanes, which write SGPRs)."""
-    op, _, rest = ins.partition(' ')
-    if not op.startswith('v_') or op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane', 'v_nop')):
-        return set()
-    return _regs(rest.split(',')[0].strip())
-
-
-def store_hazards(body, window=2):
-    """buffer_store_dwordx3/x4 with an SGPR soffset followed, within `window` wait states, by a VALU write to the
-    store's data registers.  Every instruction counts as one wait state, s_nop N as N + 1."""
-    bad = []
-    for i, ins in enumerate(body):
-        m = re.match(r'buffer_store_dwordx[34]\s+(v\[\d+:\d+\]),\s*([^,]+),\s*(s\[\d+:\d+\]),\s*(\S+)', ins)
-        if not m:
-            continue
-        soffset = m.group(4).rstrip(',')
-        if not re.fullmatch(r's\d+|m0|ttmp\d+', soffset):           # constant soffset: hipcc inserts the wait states itself
-            continue
-        data, ws, j = _regs(m.group(1)), 0, i + 1
-        while j < len(body) and ws < window:
-            nxt = body[j]
-            if _valu_dest(nxt) & data:
-                bad.append((ins, nxt))
-                break
-            mm = re.match(r's_nop\s+(\d+)', nxt)
-            ws += int(mm.group(1)) + 1 if mm else 1
-            j += 1
-    return bad
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():

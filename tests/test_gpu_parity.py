@@ -355,6 +355,36 @@ def test_512_mixed_masks_vs_oracle(P):
         assert rel_l2(xl[b], O.admm_l1(y64, masks[mid[b]], 30, 0.1, 0.015)) <= 1e-5
 
 
+def test_config5_at_its_per_gpu_size(P):
+    """BASELINE.json configs[4] as one GPU of the 8 sees it: 256 slices of 512x512, mask bank of 3 (mask_id = b % 3), the
+    default chunked schedule (16-slice chunks round-robin over 4 HIP queues, `plan`), 6 CNC iterations: first, middle and
+    last slice against the oracle <= 1e-5, the whole batch bit-identical to the unchunked schedule (chunk = -1)."""
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    H = W = 512
+    B = 256
+    masks = np.stack([S.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+    mid = (np.arange(B) % 3).astype(np.int32)
+    img, noise = S.batch(7000, B, H, W)
+    res = {}
+    with P.Engine(H, W, Bmax=B) as eng:
+        eng.synthesize(img, noise, masks, mid)
+        assert eng.path_name == 'fused'
+        assert eng.plan == {'queues': 4, 'chunk': 16, 'launches_per_iteration': 32}
+        y_all = eng.download_y()
+        for chunk in (0, -1):
+            eng.set_schedule(queues=2, mixed_launches=False, chunk=chunk)
+            eng.init_state()
+            eng.admm_cnc(6, 0.45, 0.5, 0.05, 64)
+            res[chunk] = eng.x().copy()
+        eng.set_schedule(queues=2, mixed_launches=False, chunk=-1)
+        assert eng.plan['chunk'] == B and eng.plan['queues'] == 1
+    assert np.array_equal(res[0], res[-1])                                      # scheduling never changes a bit
+    assert np.isfinite(res[0]).all()
+    for b in (0, B // 2 - 1, B - 1):
+        ref = O.admm_cnc(y_all[b].astype(np.complex128), masks[mid[b]], 6, 0.45, 0.5, 0.05, 64)
+        assert rel_l2(res[0][b], ref) <= 1e-5, (b, rel_l2(res[0][b], ref))
+
+
 def test_run_is_resumable_and_deterministic(P, golden_inputs):
     """10 + 15 iterations == 25 iterations bit for bit; two runs agree bit for bit."""
     masks = _masks(golden_inputs)
