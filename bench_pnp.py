@@ -42,6 +42,8 @@ def main():
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
     ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'], help='autocast throughput mode, off parity')
+    ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip'],
+                    help="hip = the 64-channel conv3x3 body layers of the plain stacks (FFDNet, DnCNN) on libpnpmri.so's fp32-MFMA kernel")
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True for the whole run')
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)))
     ap.add_argument('--rehearse-gloo', action='store_true', help='N > 1 on a box with ONE GPU: gloo backend, all ranks on cuda:0')
@@ -92,7 +94,8 @@ def main():
     sig = None
     if sched:
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
-    den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype).to(dev)
+    den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype,
+                     backend=args.cnn_backend).to(dev)
     flop_per_call = D.forward_flops(den, H, W, dev)     # one slice, one D(.)
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)
@@ -161,7 +164,7 @@ def main():
             'dtype': 'f32' if args.cnn_dtype is None else args.cnn_dtype, 'data': 'synthetic (seeded weights)',
             'config': {'workload': 'PNP_ADMM_CNC_D, %s, %d synthetic %dx%d slices per GPU, %s, S6:569-577 presets'
                                    % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
-                       'cnn_batch': args.cnn_batch},
+                       'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend},
             'slice_iterations_per_s': world * K * B / wall, 'gather_ms': gather_ms,
             'per_rank': None if dist is None else {'ms_per_step': [float(v) / K * 1e3 for v in per_rank[:, 0]],
                                                    'gather_ms': [float(v) for v in per_rank[:, 3]]},
@@ -174,7 +177,8 @@ def main():
                          'flop_per_call_per_slice': flop_per_call, 'flop_per_step': den_flop,
                          'roofline': {'bound': 'mfma_f32', 'achieved': den_gflops, 'peak': F32_MATRIX_PEAK_GFLOPS, 'unit': 'GFLOP/s',
                                       'frac': den_gflops / F32_MATRIX_PEAK_GFLOPS},
-                         'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)'},
+                         'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)' if args.cnn_backend == 'torch' else
+                                 'body layers (64 -> 64 conv3x3 + ReLU) on the fp32-MFMA implicit GEMM of libpnpmri.so (kernels_conv.hip); first / last layer PyTorch-ROCm'},
             'x_finite': bool(torch.isfinite(x).all())}) + '\n')
         out.flush()
     eng.close()

@@ -883,6 +883,27 @@ int pnp_download_x_f64(pnp_ctx* c, double* x, int on_device) {
 
 int pnp_is_f64(pnp_ctx* c) { return (c && c->f64) ? 1 : 0; }
 
+/* ---- optional HIP backend of the denoisers' 64-channel body layers (no ctx: caller-owned device tensors) ---- */
+int pnp_conv3x3_c64_nhwc(void* stream, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                         int n, int H, int W, int relu) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: null pointer");
+    if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: n, H, W must be >= 1");
+    if (x == y || skip == y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: y must not alias x or skip (tiles read their neighbours' halo)");
+    HIPCHK(launch_conv3x3_c64((hipStream_t)stream, x, w, bias, skip, y, n, H, W, relu));
+    return PNP_OK;
+}
+int pnp_conv3x3_c64_pack(void* stream, const float* w_oihw, float* w_packed) {
+    if (!w_oihw || !w_packed || w_oihw == w_packed) return fail(PNP_E_ARG, "pnp_conv3x3_c64_pack: null or aliased pointers");
+    HIPCHK(launch_conv_pack_w((hipStream_t)stream, w_oihw, w_packed));
+    return PNP_OK;
+}
+int pnp_relayout_c64(void* stream, const float* in, float* out, int n, int H, int W, int to_nhwc) {
+    if (!in || !out || in == out) return fail(PNP_E_ARG, "pnp_relayout_c64: null or aliased pointers");
+    if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_relayout_c64: n, H, W must be >= 1");
+    HIPCHK(launch_relayout64((hipStream_t)stream, in, out, n, H * W, to_nhwc != 0));
+    return PNP_OK;
+}
+
 int pnp_timer_start(pnp_ctx* c) { CTX(c); HIPCHK(hipEventRecord(c->ev0, c->stream)); return PNP_OK; }
 int pnp_timer_stop(pnp_ctx* c, float* ms) {
     CTX(c);

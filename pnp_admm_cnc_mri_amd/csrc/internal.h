@@ -73,6 +73,12 @@ hipError_t upload_gauss();
 template <typename X> hipError_t launch_ssim(hipStream_t s, const X* x, const uint8_t* gt, double* partial /*[B][tiles]*/, int B, int H, int W);
 hipError_t launch_widen(hipStream_t s, const float* in, double* out, size_t n);      // float -> double, n % 4 == 0
 
+// optional HIP backend of the denoisers' 64-channel conv3x3 body layers (kernels_conv.hip); activations NHWC float32
+hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw /*[64][64][3][3]*/, float* wfrag /*36 864 floats*/);
+hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
+                              float* y, int n, int H, int W, int relu);
+hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc);
+
 // How the fused loops are scheduled (scheduling only: results are bit-identical for every setting).
 struct FusedSchedule {
     int queues = 2;         // HIP queues the batch is split over (1..4); kernel heads/tails overlap

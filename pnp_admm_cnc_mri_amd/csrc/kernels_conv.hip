@@ -1,0 +1,307 @@
+// Optional HIP backend of the denoisers' plain convolution stacks (FFDNet, DnCNN: models/network_ffdnet.py:58-73,
+// models/network_dncnn.py:36-67, both built from models/basicblock.py:63-100 `conv(..., mode='CR')`): one kernel,
+//
+//     y = relu?( conv3x3(x, w) + bias ),   64 -> 64 channels, stride 1, zero padding 1, float32,
+//
+// as an implicit GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact f32 fma chains at the f32 vector
+// peak, 64 FLOP/clk/SIMD -- MI355X has no TF32-like shortcut).  The north star keeps the CNN forward in PyTorch-ROCm; this
+// is the opt-in `Denoiser(backend='hip')` for the 64-channel body layers, where configs 3-5 spend 99.8 % of their time.
+//
+//   layout   activations NHWC ([image][row][col][64 channels]): the K direction of the GEMM (input channels of one tap) is
+//            contiguous, a pixel is 256 bytes; weights packed once per model into fragment order by pnp_conv3x3_c64_pack
+//   tile     one 256-thread workgroup = 8 x 16 output pixels x 64 output channels of one image; wave w owns rows 2w, 2w+1
+//            (32 pixels = the M of one MFMA) x both halves of the output channels: 2 accumulator tiles = 32 VGPRs.
+//            45 KiB of LDS, 2 waves per SIMD by registers: TWO workgroups per compute unit, one's staging and epilogue run
+//            under the other's MFMAs (a 16 x 16 tile with one 512-thread workgroup per unit: 0.70 of the matrix peak)
+//   K loop   9 taps x 64 input channels.  The 10 x 18 x 64 input tile (halo included, zero-filled outside the image) stays in
+//            LDS for the whole tile; the weights stream from L2 straight into registers in MFMA-fragment order (k_conv_pack_w),
+//            three operand groups ahead of their use -- no weight staging, no barrier inside a tile's 576 MFMAs per wave
+//   operands one ds_read_b128 per lane = four consecutive input channels = the A (or B) operand of FOUR MFMA steps: lane
+//            (i, kh) of v_mfma_f32_32x32x2_f32 supplies A[i][k = kh], so lane half kh reads channels 8 g + 4 kh .. + 3 of
+//            group g and step e = 0..3 pairs channel 8 g + e with 8 g + 4 + e -- the same on the weight side, so the K order
+//            is consistent.  LDS images are XOR-swizzled on the 16-byte chunk index (chunk ^ (pixel & 15)): the 16 lanes a
+//            b128 access serves per cycle hit 16 distinct 4-bank groups.
+//   epilogue bias + ReLU on the accumulators, 128-byte row segments per (pixel, half of the channels)
+#include "internal.h"
+#include <hip/hip_runtime.h>
+
+namespace pnp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef CV_MT_N
+#define CV_MT_N 1
+#endif
+constexpr int CV_MT = CV_MT_N;                 // M tiles (of 32 pixels = 2 tile rows) per wave: 1 -> 8 x 16 tiles, two workgroups per unit; 2 -> 16 x 16, one
+constexpr int CV_TX = 16, CV_TY = 8 * CV_MT;   // output tile
+constexpr int CV_HX = CV_TX + 2, CV_HY = CV_TY + 2;      // with halo
+constexpr int CV_C = 64;                       // channels in and out
+constexpr int CV_XIN = CV_HY * CV_HX * CV_C;   // floats of the input tile: 46 080 bytes (MT = 1)
+constexpr int CV_THREADS = 256;
+constexpr int CV_GROUPS = 9 * 8;               // operand groups per tile: 9 taps x 8 groups of 8 input channels
+constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packed weights (= 9 * 64 * 64)
+#ifndef CV_BD_N
+#define CV_BD_N 3
+#endif
+constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of 8 register slots)
+#ifndef CV_ABLATE
+#define CV_ABLATE 0                            // timing experiments (wrong results): 1 no A reads, 2 no B loads, 4 neither, 3 no epilogue stores, 5 no input prefetch
+#endif
+
+struct ConvArgs {
+    const float* x;       // [n][H][W][64]
+    const float* w;       // packed: [group G = tap * 8 + g][N tile 2][lane 64][4]  (k_conv_pack_w)
+    const float* bias;    // [64] or null
+    const float* skip;    // [n][H][W][64] or null: added AFTER bias (and before the ReLU, if any) -- residual blocks
+    float* y;             // [n][H][W][64]
+    int n, H, W, tiles_x, tiles_y, relu;
+};
+
+// float offset of (pixel p of the tile, 16-byte chunk cq) in the swizzled input image
+__device__ __forceinline__ int sw(int p, int cq) { return p * CV_C + ((cq ^ (p & 15)) << 2); }
+
+// where tile `t` of the launch lies
+struct TilePos { int img, y0, x0; };
+__device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
+    const int per_img = a.tiles_x * a.tiles_y;
+    TilePos q;
+    q.img = t / per_img;
+    const int trem = t - q.img * per_img, ty = trem / a.tiles_x;
+    q.y0 = ty * CV_TY; q.x0 = (trem - ty * a.tiles_x) * CV_TX;
+    return q;
+}
+
+constexpr int CV_XU = (CV_HY * CV_HX * 16 + CV_THREADS - 1) / CV_THREADS;     // 16-byte chunks of the input tile per thread (12)
+
+// the input tile of `q` (halo included, zeros outside the image): global -> registers
+__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, int tid, f32x4 (&v)[CV_XU]) {
+    const float* xb = a.x + (size_t)q.img * a.H * a.W * CV_C;
+#pragma unroll
+    for (int u = 0; u < CV_XU; ++u) {
+        const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15, r = p / CV_HX, c = p - r * CV_HX;
+        const int gy = q.y0 - 1 + r, gx = q.x0 - 1 + c;
+        const bool in = idx < CV_HY * CV_HX * 16 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        v[u] = in ? *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * a.W + gx) * CV_C + cq * 4) : zero;
+    }
+}
+__device__ __forceinline__ void put_input(float* xin, int tid, const f32x4 (&v)[CV_XU]) {
+#pragma unroll
+    for (int u = 0; u < CV_XU; ++u) {
+        const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15;
+        if (idx < CV_HY * CV_HX * 16) *reinterpret_cast<f32x4*>(xin + sw(p, cq)) = v[u];
+    }
+}
+
+// Persistent workgroups (two per compute unit): workgroup b works through tiles b, b + gridDim, ...
+//   * the INPUT tile (10 x 18 pixels x 64 channels, halo included) lives in LDS; while the matrix cores run tile T, tile
+//     T + 1's input is already on its way from memory into registers;
+//   * the WEIGHTS never touch LDS: they are packed once per model in MFMA-fragment order (k_conv_pack_w), so that the B
+//     operands of one group of four MFMA steps are ONE contiguous 1 KiB wave load per half of the output channels, the same
+//     147 KiB for every workgroup (L2-resident), requested CV_BD groups ahead of their use -- an endless periodic stream
+//     (group 72 of a tile is group 0 of the next).  With the weight slices staged through LDS a workgroup needed a barrier
+//     per tap: 0.78 of the matrix peak, the matrix pipe idle a fifth of the time; without, three barriers per tile.
+__global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c64(ConvArgs a, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float xin[CV_XIN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int prow = 2 * CV_MT * wv + (i >> 4), pcol = i & 15;  // this lane's pixel of the wave's first M tile (tile coordinates); tile mt: + 2 mt rows
+    const float bias0 = a.bias ? a.bias[i] : 0.f, bias1 = a.bias ? a.bias[i + 32] : 0.f;
+    const f32x4* wl = reinterpret_cast<const f32x4*>(a.w) + lane;          // + (2 G + nt) * 64: this lane's fragment of group G
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    f32x4 xpre[CV_XU];
+    fetch_input(a, tile_pos(a, tile), tid, xpre);
+    put_input(xin, tid, xpre);
+    // weight fragments of the first CV_BD groups; ring slot = G % 8 (8 groups per tap: the slot of a group is static)
+    f32x4 bq0[8], bq1[8];
+#pragma unroll
+    for (int d = 0; d < CV_BD; ++d) { bq0[d] = wl[(2 * d) * 64]; bq1[d] = wl[(2 * d + 1) * 64]; }
+    __syncthreads();
+    // Two workgroups share a compute unit and run the same program: started together they would load, compute and store
+    // together, and the matrix cores would idle through every epilogue.  The one that arrived second on its SIMD (wave slot
+    // != 0: HW_REG_HW_ID[3:0]) starts half a tile late, once; after that the two stay out of phase.  Speed only.
+    if (CV_MT == 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+
+#pragma unroll 1
+    for (; tile < ntiles; tile += gridDim.x) {
+        const TilePos q = tile_pos(a, tile);
+        const bool more = tile + (int)gridDim.x < ntiles;
+#if CV_ABLATE != 5
+        if (more) fetch_input(a, tile_pos(a, tile + gridDim.x), tid, xpre);     // consumed after this tile's nine taps
+#endif
+        f32x16 acc0[CV_MT], acc1[CV_MT];
+#pragma unroll
+        for (int mt = 0; mt < CV_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[mt][r] = 0.f; acc1[mt][r] = 0.f; }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int p = (prow + ky) * CV_HX + pcol + kx;       // input pixel of this tap
+            const float* ap = xin + p * CV_C;
+            const int psw = p & 15;
+            // the weight stream is periodic in 72 groups; (tap * 8 + g + CV_BD) % 72 without a division
+            int gpre = tap * 8 + CV_BD;
+            // A operands double-buffered in registers: group g + 1's 16-byte read is ISSUED before group g's eight MFMAs and
+            // lands under them (left to itself hipcc sinks each read to just before its use)
+            // (M tile mt of the wave lies 2 mt tile rows = 2 mt * 18 pixels further: p + 36 mt keeps p & 15 + 4 mt)
+            f32x4 av[2][CV_MT];
+#pragma unroll
+            for (int mt = 0; mt < CV_MT; ++mt) av[0][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_C + ((kh ^ ((p + 2 * mt * CV_HX) & 15)) << 2));
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+#if CV_ABLATE != 1 && CV_ABLATE != 4
+                if (g + 1 < 8) {
+#pragma unroll
+                    for (int mt = 0; mt < CV_MT; ++mt)
+                        av[nxt][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_C + (((2 * (g + 1) + kh) ^ ((p + 2 * mt * CV_HX) & 15)) << 2));
+                }
+#endif
+#if CV_ABLATE != 2 && CV_ABLATE != 4
+                {
+                    int G = gpre + g;
+                    G = G >= CV_GROUPS ? G - CV_GROUPS : G;
+                    bq0[(g + CV_BD) & 7] = wl[(2 * G) * 64];
+                    bq1[(g + CV_BD) & 7] = wl[(2 * G + 1) * 64];
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int mt = 0; mt < CV_MT; ++mt) {
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt][e], bq0[g][e], acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt][e], bq1[g][e], acc1[mt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                             // every wave is done with this tile's input
+
+        // ---- epilogue.  Accumulator (reg r, lane) = pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32, channel
+        // lane & 31 (+ 32 for the second tile).  Stored straight from there every lane would issue 32 dword stores per tile,
+        // and such a tail is bound by store ISSUE, not by bandwidth: the wave's 32 x 64 outputs go through its own 8 KiB of the
+        // (now idle) input tile instead and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes.
+        // The skip input joins there; bias before, ReLU after.
+        float* stage = xin + wv * (32 * CV_C);
+        float* yb = a.y + (size_t)q.img * a.H * a.W * CV_C;
+        const float* sb = a.skip ? a.skip + (size_t)q.img * a.H * a.W * CV_C : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < CV_MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                stage[m * CV_C + i] = acc0[mt][r] + bias0;
+                stage[m * CV_C + i + 32] = acc1[mt][r] + bias1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int cq = lane & 15;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = 4 * it + (lane >> 4);                  // pixel of the M tile: row m >> 4, column m & 15
+                const int gy = q.y0 + 2 * CV_MT * wv + 2 * mt + (m >> 4), gx = q.x0 + (m & 15);
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + m * CV_C + cq * 4);
+                if (gy < a.H && gx < a.W) {
+                    const size_t o = ((size_t)gy * a.W + gx) * CV_C + cq * 4;
+                    if (sb) v += *reinterpret_cast<const f32x4*>(sb + o);
+                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+#if CV_ABLATE != 3
+                    *reinterpret_cast<f32x4*>(yb + o) = v;
+#else
+                    if (v[0] == 1234.5f) *reinterpret_cast<f32x4*>(yb + o) = v;
+#endif
+                }
+            }
+            if (mt + 1 < CV_MT) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        if (more) {
+            __syncthreads();                                         // every wave is done with the staging area
+            put_input(xin, tid, xpre);
+            __syncthreads();
+        }
+    }
+}
+
+// torch.nn.Conv2d weight [64 out][64 in][3][3] -> the kernel's fragment order: element e of lane (i, kh) of group G = tap * 8 + g,
+// N tile nt is W[out = 32 nt + i][in = 8 g + 4 kh + e][ky][kx], tap = 3 ky + kx  (v_mfma_f32_32x32x2_f32: lane l supplies
+// B[k = l >> 5][column l & 31]; the A side reads input channels in the same order).  Once per model.
+__global__ __launch_bounds__(256) void k_conv_pack_w(const float* w_oihw, float* wfrag) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= CV_WFRAG) return;
+    const int e = o & 3, lane = (o >> 2) & 63, nt = (o >> 8) & 1, G = o >> 9;
+    const int tap = G >> 3, g = G & 7, i = lane & 31, kh = lane >> 5;
+    const int out = 32 * nt + i, in = 8 * g + 4 * kh + e;
+    wfrag[o] = w_oihw[((size_t)out * 64 + in) * 9 + tap];
+}
+
+// NCHW <-> NHWC for 64-channel activations (the stacks' first and last layers stay with PyTorch in NCHW): one block per
+// (image, 64-pixel run); 64 x 64 tile through LDS, both sides coalesced.
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void k_relayout64(const float* in, float* out, int HW) {
+    __shared__ float t[64][65];
+    const int img = blockIdx.y, p0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float* ib = in + (size_t)img * HW * 64;
+    float* ob = out + (size_t)img * HW * 64;
+    for (int e = tid; e < 4096; e += 256) {
+        const int a_ = e >> 6, b_ = e & 63;                       // input: rows of 64 contiguous elements
+        if (TO_NHWC) { const int c = a_, p = p0 + b_; t[c][b_] = p < HW ? ib[(size_t)c * HW + p] : 0.f; }
+        else         { const int p = p0 + a_, c = b_; t[b_][a_] = p < HW ? ib[(size_t)p * 64 + c] : 0.f; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+        const int a_ = e >> 6, b_ = e & 63;
+        if (TO_NHWC) { const int p = p0 + a_, c = b_; if (p < HW) ob[(size_t)p * 64 + c] = t[c][a_]; }
+        else         { const int c = a_, p = p0 + b_; if (p < HW) ob[(size_t)c * HW + p] = t[c][b_]; }
+    }
+}
+
+hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                              int n, int H, int W, int relu) {
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu;
+    a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
+    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // persistent workgroups, two per compute unit (77 KiB of LDS each); every workgroup's loop ends: tile < ntiles
+    const long long resident = (CV_MT == 1 ? 2LL : 1LL) * cus[dev];
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    hipLaunchKernelGGL(k_conv3x3_c64, dim3(grid), dim3(CV_THREADS), 0, s, a, (int)tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw, float* wfrag) {
+    hipLaunchKernelGGL(k_conv_pack_w, dim3(CV_WFRAG / 256), dim3(256), 0, s, w_oihw, wfrag);
+    return hipGetLastError();
+}
+
+hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc) {
+    const dim3 grid((HW + 63) / 64, n);
+    if (to_nhwc) hipLaunchKernelGGL(k_relayout64<true>, grid, dim3(256), 0, s, in, out, HW);
+    else         hipLaunchKernelGGL(k_relayout64<false>, grid, dim3(256), 0, s, in, out, HW);
+    return hipGetLastError();
+}
+
+}  // namespace pnp

@@ -37,22 +37,98 @@ def _conv_stack(in_nc, out_nc, nc, nb, dilations=None):
     return nn.Sequential(*L)
 
 
-class DnCNN(nn.Module):
+# ----------------------------------------------------------------------------------------------
+# Optional HIP backend of the plain stacks (`Denoiser(backend='hip')`): the 64 -> 64 conv3x3 + ReLU body layers -- 97 % of
+# FFDNet's and DnCNN's arithmetic -- run on libpnpmri.so's fp32-MFMA implicit GEMM (csrc/kernels_conv.hip, 0.78 of the fp32
+# matrix peak at 64 x 64 x 128 x 128 against MIOpen's 0.57) with activations in NHWC; the first and the last layer (1..5 -> 64,
+# 64 -> 1..4 channels) stay with PyTorch.  Same weights, same state_dict; the default backend is PyTorch-ROCm / MIOpen.
+# ----------------------------------------------------------------------------------------------
+def _hip_body_ok(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.in_channels == 64 and conv.out_channels == 64 and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == 'zeros')
+
+
+def _hip_weights(seq, k, conv, L, stream):
+    """conv.weight packed into the HIP kernel's fragment order (pnp_conv3x3_c64_pack), rebuilt when the parameter changes
+    (load_state_dict, bank switches).  Kept outside the state_dict."""
+    import ctypes as C
+    from . import _lib
+    cache = seq.__dict__.setdefault('_pnp_hip_w', {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    hit = cache.get(k)
+    if hit is None or hit[0] != key:
+        src = w.detach().contiguous()                          # [out][in][3][3] whatever the parameter's memory format
+        packed = torch.empty(9 * 64 * 64, dtype=torch.float32, device=w.device)
+        _lib.check(L.pnp_conv3x3_c64_pack(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr())))
+        cache[k] = hit = (key, packed)
+    return hit[1]
+
+
+def hip_stack_forward(seq, x):
+    """`seq(x)` for a [Conv3x3, ReLU] * (nb - 1) + Conv3x3 stack with its eligible 64 -> 64 layers on the HIP kernel.
+    Raises if the library or a GPU tensor is missing: no silent fallback to another device; layers the kernel does not cover
+    (other channel counts, dilations) run in PyTorch inside the same call."""
+    import ctypes as C
+    from . import _lib
+    if not (x.is_cuda and x.dtype == torch.float32):
+        raise RuntimeError("Denoiser(backend='hip') needs float32 CUDA tensors")
+    L = _lib.lib()
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    mods = list(seq)
+    h, nhwc, k = x, None, 0                                    # h: NCHW tensor, or nhwc: [n][H][W][64] between HIP layers
+    while k < len(mods):
+        m = mods[k]
+        relu = k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU)
+        if _hip_body_ok(m):
+            if nhwc is None:
+                hp = h.permute(0, 2, 3, 1)
+                if hp.is_contiguous():                         # channels_last tensor: already NHWC in memory
+                    nhwc = hp
+                else:
+                    nhwc = torch.empty(hp.shape, dtype=h.dtype, device=h.device)
+                    _lib.check(L.pnp_relayout_c64(stream, C.c_void_p(h.contiguous().data_ptr()), C.c_void_p(nhwc.data_ptr()),
+                                                  h.shape[0], h.shape[2], h.shape[3], 1))
+            n, H, W, _ = nhwc.shape
+            out = torch.empty_like(nhwc)
+            bias = None if m.bias is None else C.c_void_p(m.bias.data_ptr())
+            _lib.check(L.pnp_conv3x3_c64_nhwc(stream, C.c_void_p(nhwc.data_ptr()), C.c_void_p(_hip_weights(seq, k, m, L, stream).data_ptr()), bias,
+                                              None, C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0))
+            nhwc = out
+            k += 2 if relu else 1
+            continue
+        if nhwc is not None:
+            h, nhwc = nhwc.permute(0, 3, 1, 2), None           # a channels_last NCHW view: PyTorch takes it as it is
+        h = m(h)
+        k += 1
+    return h if nhwc is None else nhwc.permute(0, 3, 1, 2)
+
+
+class _PlainStack(nn.Module):
+    """shared by DnCNN / FDnCNN / FFDNet: `self.model` is the conv stack, `backend` selects who runs its body"""
+    backend = 'torch'
+
+    def _stack(self, x):
+        return hip_stack_forward(self.model, x) if self.backend == 'hip' else self.model(x)
+
+
+class DnCNN(_PlainStack):
     def __init__(self, in_nc=1, out_nc=1, nc=64, nb=17):
         super().__init__()
         self.model = _conv_stack(in_nc, out_nc, nc, nb)
 
     def forward(self, x):
-        return x - self.model(x)
+        return x - self._stack(x)
 
 
-class FDnCNN(nn.Module):
+class FDnCNN(_PlainStack):
     def __init__(self, in_nc=2, out_nc=1, nc=64, nb=20):
         super().__init__()
         self.model = _conv_stack(in_nc, out_nc, nc, nb)
 
     def forward(self, x):
-        return self.model(x)
+        return self._stack(x)
 
 
 class IRCNN(nn.Module):
@@ -64,7 +140,7 @@ class IRCNN(nn.Module):
         return x - self.model(x)
 
 
-class FFDNet(nn.Module):
+class FFDNet(_PlainStack):
     def __init__(self, in_nc=1, out_nc=1, nc=64, nb=15):
         super().__init__()
         self.model = _conv_stack(in_nc * 4 + 1, out_nc * 4, nc, nb)
@@ -76,18 +152,48 @@ class FFDNet(nn.Module):
         x = F.pad(x, (0, int(math.ceil(w / 2) * 2 - w), 0, int(math.ceil(h / 2) * 2 - h)), mode='replicate')
         x = F.pixel_unshuffle(x, 2)
         m = sigma.to(x.dtype).expand(x.shape[0], 1, x.shape[-2], x.shape[-1])
-        x = self.model(torch.cat((x, m), 1))
+        x = self._stack(torch.cat((x, m), 1))
         x = F.pixel_shuffle(x, 2)
         return x[..., :h, :w]
 
 
+def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu):
+    import ctypes as C
+    from . import _lib
+    out = torch.empty_like(x_nhwc)
+    n, H, W, _ = x_nhwc.shape
+    _lib.check(L.pnp_conv3x3_c64_nhwc(stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()),
+                                      None if bias is None else C.c_void_p(bias.data_ptr()),
+                                      None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()),
+                                      C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0))
+    return out
+
+
 class _ResBlock(nn.Module):
+    """x + conv(relu(conv(x))), bias-free (models/basicblock.py:213-225, mode 'CRC').  With backend 'hip' the 64-channel
+    blocks (DRUNet's full-resolution scale: 28 % of its arithmetic, where MIOpen's fp32 kernels are at their slowest) run on
+    libpnpmri.so's conv kernel, the residual add fused into the second convolution's epilogue."""
+    backend = 'torch'
+
     def __init__(self, nc):
         super().__init__()
         self.res = nn.Sequential(nn.Conv2d(nc, nc, 3, 1, 1, bias=False), nn.ReLU(inplace=True),
                                  nn.Conv2d(nc, nc, 3, 1, 1, bias=False))
 
     def forward(self, x):
+        if self.backend == 'hip' and _hip_body_ok(self.res[0]) and _hip_body_ok(self.res[2]):
+            import ctypes as C
+            from . import _lib
+            if not (x.is_cuda and x.dtype == torch.float32):
+                raise RuntimeError("Denoiser(backend='hip') needs float32 CUDA tensors")
+            L = _lib.lib()
+            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            xn = x.permute(0, 2, 3, 1)
+            if not xn.is_contiguous():
+                xn = xn.contiguous()                           # NCHW-contiguous input: one copy; channels_last tensors pass as they are
+            h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream), self.res[0].bias, None, True)
+            y = _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream), self.res[2].bias, xn, False)
+            return y.permute(0, 3, 1, 2)                       # a channels_last NCHW view
         return x + self.res(x)
 
 
@@ -246,11 +352,16 @@ def forward_flops(den, H, W, device):
             macs[0] += out.numel() * (m.in_channels // m.groups) * kh * kw
 
     hs = [m.register_forward_hook(hook) for m in den.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+    swapped = [m for m in den.model.modules() if getattr(m, 'backend', None) == 'hip']
+    for m in swapped:
+        m.backend = 'torch'                  # the probe counts module calls; the HIP backend does the same arithmetic outside them
     try:
         den(torch.rand((1, 1, H, W), dtype=torch.float32, device=device), 0)
     finally:
         for h in hs:
             h.remove()
+        for m in swapped:
+            m.backend = 'hip'
     return 2 * macs[0]
 
 
@@ -259,9 +370,22 @@ class Denoiser:
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
 
     def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
-                 cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto'):
+                 cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch'):
+        """backend: 'torch' (default: the whole forward in PyTorch-ROCm / MIOpen, as the north star keeps it) or 'hip' (the
+        64 -> 64 conv3x3 + ReLU body layers of DnCNN / FDnCNN / FFDNet, and DRUNet's 64-channel residual blocks, on
+        libpnpmri.so's fp32-MFMA kernel, float32 only; IRCNN's dilated layers are unaffected)."""
+        if backend not in ('torch', 'hip'):
+            raise ValueError("backend must be 'torch' or 'hip'")
+        if backend == 'hip' and cnn_dtype not in (None, 'fp32'):
+            raise ValueError("backend='hip' is float32 only")
         self.name, self.fam = model_name, family(model_name)
         self.model = model
+        self.backend = backend
+        if isinstance(model, _PlainStack):
+            model.backend = backend
+        for m in model.modules():
+            if isinstance(m, _ResBlock):
+                m.backend = backend
         self.noise_level_model = noise_level_model
         self.sigmas = sigmas              # torch tensor [iter_num] (drunet / ircnn)
         self.x8 = x8

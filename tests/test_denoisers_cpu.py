@@ -164,3 +164,24 @@ def test_forward_flops_match_the_survey(name, gflop):
     den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=np.zeros((256, 256), np.complex64), miopen_find=False)
     got = D.forward_flops(den, 256, 256, 'cpu') / 1e9
     assert abs(got - gflop) <= 0.02 * gflop, got
+
+
+def test_hip_backend_needs_gpu_tensors_and_float32():
+    """`Denoiser(backend='hip')` never computes on the CPU: a CPU tensor raises; autocast modes are refused; the default
+    backend is PyTorch."""
+    import pytest as _pytest
+    from pnp_admm_cnc_mri_amd import denoisers as D
+    net, nlm, _ = D.build('ffdnet_gray')
+    net.load_state_dict(D.seeded_state_dict(net, 1))
+    assert D.Denoiser('ffdnet_gray', net.eval(), nlm).backend == 'torch' and net.backend == 'torch'
+    den = D.Denoiser('ffdnet_gray', net.eval(), nlm, backend='hip', miopen_find=False)
+    assert net.backend == 'hip'
+    with _pytest.raises(RuntimeError, match='CUDA'):
+        den(torch.rand(1, 1, 32, 32), 0)
+    with _pytest.raises(ValueError):
+        D.Denoiser('ffdnet_gray', net, nlm, backend='hip', cnn_dtype='bf16')
+    with _pytest.raises(ValueError):
+        D.Denoiser('ffdnet_gray', net, nlm, backend='cuda')
+    # the body layers the kernel takes: 13 of FFDNet's 15, 15 of DnCNN-17's, none of IRCNN's dilated ones
+    count = lambda m: sum(1 for c in m.model if D._hip_body_ok(c))
+    assert count(net) == 13 and count(D.build('dncnn_15')[0]) == 15 and count(D.build('ircnn_gray')[0]) == 0

@@ -1,0 +1,126 @@
+"""The optional HIP backend of the denoisers' plain conv stacks (csrc/kernels_conv.hip, `Denoiser(backend='hip')`): the
+64 -> 64 conv3x3 (+ bias, + skip, + ReLU) implicit GEMM on the fp32 matrix cores against a plain PyTorch reference of the
+same op.  fp32 MFMA is an exact f32 fma chain over the 576 products of an output value, so one layer sits at ~5e-7 from the
+float64 result -- the same distance as MIOpen's own fp32 kernels; tolerances: one layer <= 2e-6 (vs float64), whole networks
+<= 1e-5 (vs the PyTorch / MIOpen forward with the same weights)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import torch.nn.functional as F
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import _lib, denoisers
+    assert torch.cuda.is_available() and _lib.device_count() >= 1
+    return dict(torch=torch, F=F, P=P, L=_lib.lib(), lib=_lib, D=denoisers)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+def _conv(env, x_nhwc, w_oihw, bias, skip, relu):
+    torch, L, lib = env['torch'], env['L'], env['lib']
+    y = torch.empty_like(x_nhwc)
+    n, H, W, _ = x_nhwc.shape
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    w9 = torch.empty(9 * 64 * 64, device='cuda')
+    lib.check(L.pnp_conv3x3_c64_pack(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(w_oihw.contiguous()), p(w9)))
+    lib.check(L.pnp_conv3x3_c64_nhwc(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(x_nhwc), p(w9), p(bias), p(skip), p(y),
+                                     n, H, W, 1 if relu else 0))
+    return y
+
+
+@pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 16, 16), (1, 8, 16), (2, 5, 23), (1, 1, 1), (5, 128, 128)])
+@pytest.mark.parametrize('variant', ['bias_relu', 'plain', 'skip_relu'])
+def test_conv3x3_c64_against_pytorch(env, n, H, W, variant):
+    """tiles of 8 x 16 pixels: shapes that are no multiple of the tile, smaller than one tile, a single pixel; more tiles than
+    resident workgroups (5 x 128 x 128 = 640 tiles on 512 persistent workgroups: the loop's second trip)"""
+    torch, F = env['torch'], env['F']
+    g = torch.Generator(device='cuda').manual_seed(1000 * n + 10 * H + W)
+    x = torch.randn(n, 64, H, W, device='cuda', generator=g)
+    w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * (2.0 / 576) ** 0.5
+    b = torch.randn(64, device='cuda', generator=g) * 0.1 if variant != 'plain' else None
+    sk = torch.randn(n, 64, H, W, device='cuda', generator=g) if variant == 'skip_relu' else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if sk is not None:
+        ref = ref + sk.double()
+    if variant != 'plain':
+        ref = F.relu(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    skn = None if sk is None else sk.permute(0, 2, 3, 1).contiguous()
+    y = _conv(env, xn, w, b, skn, variant != 'plain')
+    assert _rel(y.permute(0, 3, 1, 2), ref) <= 2e-6
+    # asymmetric weights + an identity-like input catch a transposed tap or channel map: one hot input channel / pixel
+    x1 = torch.zeros(1, 64, H, W, device='cuda')
+    x1[0, 7, H // 2, W // 2] = 1.0
+    y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False)
+    assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.double(), w.double(), padding=1)) <= 1e-6
+
+
+def test_relayout_round_trip_and_argument_errors(env):
+    torch, L, lib = env['torch'], env['L'], env['lib']
+    x = torch.randn(3, 64, 37, 21, device='cuda')
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xn = torch.empty(3, 37, 21, 64, device='cuda')
+    lib.check(L.pnp_relayout_c64(s, C.c_void_p(x.data_ptr()), C.c_void_p(xn.data_ptr()), 3, 37, 21, 1))
+    assert torch.equal(xn, x.permute(0, 2, 3, 1).contiguous())
+    back = torch.empty_like(x)
+    lib.check(L.pnp_relayout_c64(s, C.c_void_p(xn.data_ptr()), C.c_void_p(back.data_ptr()), 3, 37, 21, 0))
+    assert torch.equal(back, x)
+    with pytest.raises(lib.PnpError):                        # y must not alias x: a tile reads its neighbours' halo
+        lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(xn.data_ptr()), C.c_void_p(xn.data_ptr()), None, None, C.c_void_p(xn.data_ptr()), 3, 37, 21, 0))
+    with pytest.raises(lib.PnpError):
+        lib.check(L.pnp_conv3x3_c64_nhwc(s, None, None, None, None, None, 1, 8, 8, 0))
+
+
+@pytest.mark.parametrize('name', ['ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'dncnn_gray_blind', 'drunet_gray'])
+def test_hip_backend_matches_the_pytorch_forward(env, name):
+    """Same seeded weights, `Denoiser(backend='hip')` against `backend='torch'` (MIOpen) on 5 slices of 256 x 256 -- and the
+    parameters are still the module's own: a load_state_dict after the first call reaches the kernel."""
+    torch, D = env['torch'], env['D']
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.rand(5, 1, 256, 256, device='cuda', generator=g)
+    noises = (np.random.default_rng(3).standard_normal((256, 256)) + 1j * np.random.default_rng(4).standard_normal((256, 256))) * 5
+    outs = {}
+    for backend in ('torch', 'hip'):
+        net, nlm, _ = D.build(name)
+        net.load_state_dict(D.seeded_state_dict(net, 11))
+        sig = torch.tensor([30.0 / 255, 20.0 / 255]) if name.startswith('drunet') else None
+        den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False).to('cuda')
+        outs[backend] = den(x, 0).clone()
+        if backend == 'hip':
+            net.load_state_dict(D.seeded_state_dict(net, 12))
+            again = den(x, 0).clone()
+            net2, _, _ = D.build(name)
+            net2.load_state_dict(D.seeded_state_dict(net2, 12))
+            ref2 = D.Denoiser(name, net2.eval(), nlm, sigmas=sig, noises=noises, miopen_find=False).to('cuda')(x, 0)
+            assert _rel(again, ref2) <= 1e-5 and _rel(again, outs['hip']) > 1e-3
+    assert _rel(outs['hip'], outs['torch']) <= 1e-5, _rel(outs['hip'], outs['torch'])
+    assert torch.isfinite(outs['hip']).all()
+
+
+def test_pnp_entry_point_with_the_hip_backend(env, tmp_path):
+    """PNP_ADMM_CNC_D(..., cnn_backend='hip') -- FFDNet, S6:573 presets, 6 iterations on 3 synthetic slices -- ends where the
+    PyTorch / MIOpen backend ends (the loop contracts: 2e-5 covers the 12 forwards' accumulated difference)."""
+    P, D = env['P'], env['D']
+    from pnp_admm_cnc_mri_amd import synthetic as S, solvers_pnp as SP
+    mask = S.reference_masks()['Q_Radial30'].astype(np.uint8)
+    img, noise = S.batch(300, 3)
+    res = {}
+    for backend in ('torch', 'hip'):
+        net, _, _ = D.build('ffdnet_gray')
+        net.load_state_dict(D.seeded_state_dict(net, 1))
+        opts = dict(SP.PRESETS['PNP_ADMM_CNC_D']['ffdnet'], iter_num=6)
+        out, _ = SP.PNP_ADMM_CNC_D('ffdnet_gray', mask, noise[0], images=img, model=net, results=str(tmp_path), cnn_backend=backend,
+                                   miopen_find=False, **opts)
+        res[backend] = np.stack([out[b] for b in range(3)])
+    err = np.linalg.norm(res['hip'] - res['torch']) / np.linalg.norm(res['torch'])
+    assert err <= 2e-5, err
