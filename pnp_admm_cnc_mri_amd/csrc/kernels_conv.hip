@@ -45,9 +45,6 @@ constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packe
 #define CV_BD_N 3
 #endif
 constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of 8 register slots)
-#ifndef CV_ABLATE
-#define CV_ABLATE 0                            // timing experiments (wrong results): 1 no A reads, 2 no B loads, 4 neither, 3 no epilogue stores, 5 no input prefetch
-#endif
 
 struct ConvArgs {
     const float* x;       // [n][H][W][64]
@@ -133,9 +130,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
     for (; tile < ntiles; tile += gridDim.x) {
         const TilePos q = tile_pos(a, tile);
         const bool more = tile + (int)gridDim.x < ntiles;
-#if CV_ABLATE != 5
         if (more) fetch_input(a, tile_pos(a, tile + gridDim.x), tid, xpre);     // consumed after this tile's nine taps
-#endif
         f32x16 acc0[CV_MT], acc1[CV_MT];
 #pragma unroll
         for (int mt = 0; mt < CV_MT; ++mt)
@@ -158,21 +153,17 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int cur = g & 1, nxt = cur ^ 1;
-#if CV_ABLATE != 1 && CV_ABLATE != 4
                 if (g + 1 < 8) {
 #pragma unroll
                     for (int mt = 0; mt < CV_MT; ++mt)
                         av[nxt][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_C + (((2 * (g + 1) + kh) ^ ((p + 2 * mt * CV_HX) & 15)) << 2));
                 }
-#endif
-#if CV_ABLATE != 2 && CV_ABLATE != 4
                 {
                     int G = gpre + g;
                     G = G >= CV_GROUPS ? G - CV_GROUPS : G;
                     bq0[(g + CV_BD) & 7] = wl[(2 * G) * 64];
                     bq1[(g + CV_BD) & 7] = wl[(2 * G + 1) * 64];
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -216,11 +207,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
                     const size_t o = ((size_t)gy * a.W + gx) * CV_C + cq * 4;
                     if (sb) v += *reinterpret_cast<const f32x4*>(sb + o);
                     if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-#if CV_ABLATE != 3
                     *reinterpret_cast<f32x4*>(yb + o) = v;
-#else
-                    if (v[0] == 1234.5f) *reinterpret_cast<f32x4*>(yb + o) = v;
-#endif
                 }
             }
             if (mt + 1 < CV_MT) {

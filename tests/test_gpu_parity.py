@@ -414,6 +414,15 @@ def test_error_behaviour(P):
             eng.x()                                     # no iteration yet
         with pytest.raises(PnpError):
             eng.admm_l1(1, 0.1, 0.0)                    # reo must be > 0
+        # thresholds must be >= 0: the fast paths evaluate soft(a, c) as a - med3(a, -c, c), which is the reference's
+        # fmax(|a| - c, 0) * sign(a) (S1:18-19) for c >= 0 only -- rejected, not silently different
+        eng.init_state()
+        for bad in (lambda: eng.admm_l1(1, -0.1, 0.015), lambda: eng.admm_cnc(1, -0.45, 0.5, 0.05, 64),
+                    lambda: eng.admm_cnc(1, 0.45, -0.5, 0.05, 64), lambda: eng.admm_cnc(1, 0.45, 0.5, 0.05, 0.0)):
+            with pytest.raises(PnpError):
+                bad()
+        eng.admm_l1(1, 0.0, 0.015)                      # a zero threshold is fine: soft(a, 0) = a
+        assert np.isfinite(eng.x()).all()
 
 
 # ------------------------------------------------------------------------------------------------
