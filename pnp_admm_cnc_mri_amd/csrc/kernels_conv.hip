@@ -37,7 +37,10 @@ constexpr int CV_MT = CV_MT_N;                 // M tiles (of 32 pixels = 2 tile
 constexpr int CV_TX = 16, CV_TY = 8 * CV_MT;   // output tile
 constexpr int CV_HX = CV_TX + 2, CV_HY = CV_TY + 2;      // with halo
 constexpr int CV_C = 64;                       // channels in and out
-constexpr int CV_XIN = CV_HY * CV_HX * CV_C;   // floats of the input tile: 46 080 bytes (MT = 1)
+constexpr int CV_PS = CV_C + 4;                // floats between consecutive pixels of the LDS tile: 272 bytes, so that the 16 lanes a b128
+                                               // read serves per cycle (consecutive pixels, same channels) start 4 banks apart -- and the
+                                               // eight operand groups of a tap are IMMEDIATE offsets of one address (no per-group VALU)
+constexpr int CV_XIN = CV_HY * CV_HX * CV_PS;  // floats of the input tile: 48 960 bytes (MT = 1)
 constexpr int CV_THREADS = 256;
 constexpr int CV_GROUPS = 9 * 8;               // operand groups per tile: 9 taps x 8 groups of 8 input channels
 constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packed weights (= 9 * 64 * 64)
@@ -45,6 +48,14 @@ constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packe
 #define CV_BD_N 3
 #endif
 constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of 8 register slots)
+
+#ifdef CV_PROF
+// diagnostic build (profiles/variants.sh build kernels_conv.hip prof "-DCV_PROF"): shader-clock sums per phase, wave 0 of every workgroup
+__device__ unsigned long long g_cvprof[1024 * 8];
+#define CV_STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) psum[k] += t_ - tlast; tlast = t_; }
+#else
+#define CV_STAMP(k)
+#endif
 
 struct ConvArgs {
     const float* x;       // [n][H][W][64]
@@ -54,9 +65,6 @@ struct ConvArgs {
     float* y;             // [n][H][W][64]
     int n, H, W, tiles_x, tiles_y, relu;
 };
-
-// float offset of (pixel p of the tile, 16-byte chunk cq) in the swizzled input image
-__device__ __forceinline__ int sw(int p, int cq) { return p * CV_C + ((cq ^ (p & 15)) << 2); }
 
 // where tile `t` of the launch lies
 struct TilePos { int img, y0, x0; };
@@ -71,24 +79,49 @@ __device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
 
 constexpr int CV_XU = (CV_HY * CV_HX * 16 + CV_THREADS - 1) / CV_THREADS;     // 16-byte chunks of the input tile per thread (12)
 
-// the input tile of `q` (halo included, zeros outside the image): global -> registers
-__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, int tid, f32x4 (&v)[CV_XU]) {
-    const float* xb = a.x + (size_t)q.img * a.H * a.W * CV_C;
+// Per-thread constants of the input staging, computed ONCE: vector instructions issued beside the partner wave's MFMA
+// stream are slow and cost that stream issue slots (phase clocks, profiles/conv_variants_r04.txt), so everything that does not
+// depend on the tile is out of the loop.  Chunk u of thread tid is (tile pixel p = (tid + 256 u) >> 4, channels 4 cq ..).
+struct Staging {
+    int goff[CV_XU];     // byte offset of the chunk relative to the tile's first halo pixel (row y0 - 1, column x0 - 1), or < 0: none
+    int col[CV_XU];      // tile column of the pixel (0 .. 17): the only coordinate that needs a test (rows fall out of the buffer range)
+    int loff[CV_XU];     // float offset in the LDS tile
+};
+__device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging& st) {
 #pragma unroll
     for (int u = 0; u < CV_XU; ++u) {
         const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15, r = p / CV_HX, c = p - r * CV_HX;
-        const int gy = q.y0 - 1 + r, gx = q.x0 - 1 + c;
-        const bool in = idx < CV_HY * CV_HX * 16 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        v[u] = in ? *reinterpret_cast<const f32x4*>(xb + ((size_t)gy * a.W + gx) * CV_C + cq * 4) : zero;
+        const bool any = idx < CV_HY * CV_HX * 16;
+        st.goff[u] = any ? (r * a.W + c) * (CV_C * 4) + cq * 16 : -1;
+        st.col[u] = c;
+        st.loff[u] = any ? p * CV_PS + cq * 4 : 0;
     }
 }
-__device__ __forceinline__ void put_input(float* xin, int tid, const f32x4 (&v)[CV_XU]) {
+// the input tile of `q` (halo included, zeros outside the image): global -> registers.  Buffer loads with ONE 32-bit offset per
+// access: rows above / below the image fall outside the descriptor's range by themselves (the offset wraps or exceeds it) and
+// the hardware returns zeros; columns left / right of it get such an offset by one select -- no branch around any load.  (As
+// `in ? *ptr : zero` hipcc branched around every one of the twelve loads and waited vmcnt(0) behind each: twelve dependent
+// memory round trips per tile.)
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* base, int H, int W) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((unsigned)H * (unsigned)W * (CV_C * 4u)), 0x00020000);
+}
+__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, const Staging& st, f32x4 (&v)[CV_XU]) {
+    const __amdgpu_buffer_rsrc_t rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
+    const int origin = ((q.y0 - 1) * a.W + (q.x0 - 1)) * (CV_C * 4);            // may be negative: such offsets are out of range as unsigned
+    const int xlo = 1 - q.x0, xhi = a.W + 1 - q.x0;                              // valid tile columns: xlo <= c < xhi
 #pragma unroll
     for (int u = 0; u < CV_XU; ++u) {
-        const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15;
-        if (idx < CV_HY * CV_HX * 16) *reinterpret_cast<f32x4*>(xin + sw(p, cq)) = v[u];
+        const bool in = st.goff[u] >= 0 && st.col[u] >= xlo && st.col[u] < xhi;
+        const int off = in ? origin + st.goff[u] : -16;
+        const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
     }
+}
+__device__ __forceinline__ void put_input(float* xin, int tid, const Staging& st, const f32x4 (&v)[CV_XU]) {
+#pragma unroll
+    for (int u = 0; u < CV_XU; ++u)
+        if (tid + CV_THREADS * u < CV_HY * CV_HX * 16) *reinterpret_cast<f32x4*>(xin + st.loff[u]) = v[u];
 }
 
 // Persistent workgroups (two per compute unit): workgroup b works through tiles b, b + gridDim, ...
@@ -110,9 +143,11 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
+    Staging st;
+    staging_init(a, tid, st);
     f32x4 xpre[CV_XU];
-    fetch_input(a, tile_pos(a, tile), tid, xpre);
-    put_input(xin, tid, xpre);
+    fetch_input(a, tile_pos(a, tile), st, xpre);
+    put_input(xin, tid, st, xpre);
     // weight fragments of the first CV_BD groups; ring slot = G % 8 (8 groups per tap: the slot of a group is static)
     f32x4 bq0[8], bq1[8];
 #pragma unroll
@@ -120,43 +155,45 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
     __syncthreads();
     // Two workgroups share a compute unit and run the same program: started together they would load, compute and store
     // together, and the matrix cores would idle through every epilogue.  The one that arrived second on its SIMD (wave slot
-    // != 0: HW_REG_HW_ID[3:0]) starts half a tile late, once; after that the two stay out of phase.  Speed only.
+    // != 0: HW_REG_HW_ID[3:0]) starts a quarter of a tile late, once; after that the two stay out of phase.  Speed only.
     if (CV_MT == 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127);
+        for (int k = 0; k < 2; ++k) __builtin_amdgcn_s_sleep(127);
     }
 
+#ifdef CV_PROF
+    unsigned long long psum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
     for (; tile < ntiles; tile += gridDim.x) {
         const TilePos q = tile_pos(a, tile);
         const bool more = tile + (int)gridDim.x < ntiles;
-        if (more) fetch_input(a, tile_pos(a, tile + gridDim.x), tid, xpre);     // consumed after this tile's nine taps
+        CV_STAMP(0)
+        if (more) fetch_input(a, tile_pos(a, tile + gridDim.x), st, xpre);      // consumed after this tile's nine taps
+        CV_STAMP(1)
         f32x16 acc0[CV_MT], acc1[CV_MT];
 #pragma unroll
         for (int mt = 0; mt < CV_MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[mt][r] = 0.f; acc1[mt][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc0[mt][r] = bias0; acc1[mt][r] = bias1; }     // the bias rides in the accumulators: no add in the epilogue
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int p = (prow + ky) * CV_HX + pcol + kx;       // input pixel of this tap
-            const float* ap = xin + p * CV_C;
-            const int psw = p & 15;
+            const float* ap = xin + p * CV_PS + kh * 4;          // + 8 g: the tap's eight operand groups are immediate offsets
             // the weight stream is periodic in 72 groups; (tap * 8 + g + CV_BD) % 72 without a division
             int gpre = tap * 8 + CV_BD;
             // A operands double-buffered in registers: group g + 1's 16-byte read is ISSUED before group g's eight MFMAs and
             // lands under them (left to itself hipcc sinks each read to just before its use)
-            // (M tile mt of the wave lies 2 mt tile rows = 2 mt * 18 pixels further: p + 36 mt keeps p & 15 + 4 mt)
             f32x4 av[2][CV_MT];
 #pragma unroll
-            for (int mt = 0; mt < CV_MT; ++mt) av[0][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_C + ((kh ^ ((p + 2 * mt * CV_HX) & 15)) << 2));
+            for (int mt = 0; mt < CV_MT; ++mt) av[0][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_PS);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int cur = g & 1, nxt = cur ^ 1;
                 if (g + 1 < 8) {
 #pragma unroll
-                    for (int mt = 0; mt < CV_MT; ++mt)
-                        av[nxt][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_C + (((2 * (g + 1) + kh) ^ ((p + 2 * mt * CV_HX) & 15)) << 2));
+                    for (int mt = 0; mt < CV_MT; ++mt) av[nxt][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_PS + 8 * (g + 1));
                 }
                 {
                     int G = gpre + g;
@@ -176,7 +213,9 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        CV_STAMP(2)
         __syncthreads();                                             // every wave is done with this tile's input
+        CV_STAMP(3)
 
         // ---- epilogue.  Accumulator (reg r, lane) = pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32, channel
         // lane & 31 (+ 32 for the second tile).  Stored straight from there every lane would issue 32 dword stores per tile,
@@ -184,31 +223,45 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
         // (now idle) input tile instead and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes.
         // The skip input joins there; bias before, ReLU after.
         float* stage = xin + wv * (32 * CV_C);
-        float* yb = a.y + (size_t)q.img * a.H * a.W * CV_C;
-        const float* sb = a.skip ? a.skip + (size_t)q.img * a.H * a.W * CV_C : nullptr;
+        const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
+        const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
+        // pixel it of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
+        // rows below the image are out of the buffer's range (the store is dropped), columns right of it get such an offset
+        const int l4 = lane >> 4;
+        const int obase = ((q.y0 + 2 * CV_MT * wv) * a.W + q.x0 + l4) * (CV_C * 4) + (lane & 15) * 16;
+        const int wlim = a.W - q.x0 - l4;                            // column 4 (it & 3) valid iff < wlim
 #pragma unroll
         for (int mt = 0; mt < CV_MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                stage[m * CV_C + i] = acc0[mt][r] + bias0;
-                stage[m * CV_C + i + 32] = acc1[mt][r] + bias1;
+                stage[m * CV_C + i] = acc0[mt][r];
+                stage[m * CV_C + i + 32] = acc1[mt][r];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int cq = lane & 15;
+            int off[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * (CV_C * 4) : -16;
+            f32x4 sk[8];
+            if (a.skip) {                                            // all eight requests first: one memory round trip, not eight
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const u32x4v k = __builtin_amdgcn_raw_buffer_load_b128(rk, off[it], 0, 0);
+                    sk[it] = f32x4{__uint_as_float(k.x), __uint_as_float(k.y), __uint_as_float(k.z), __uint_as_float(k.w)};
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) sk[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int m = 4 * it + (lane >> 4);                  // pixel of the M tile: row m >> 4, column m & 15
-                const int gy = q.y0 + 2 * CV_MT * wv + 2 * mt + (m >> 4), gx = q.x0 + (m & 15);
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + m * CV_C + cq * 4);
-                if (gy < a.H && gx < a.W) {
-                    const size_t o = ((size_t)gy * a.W + gx) * CV_C + cq * 4;
-                    if (sb) v += *reinterpret_cast<const f32x4*>(sb + o);
-                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    *reinterpret_cast<f32x4*>(yb + o) = v;
-                }
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * it + l4) * CV_C + (lane & 15) * 4) + sk[it];
+                if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, off[it], 0, 0);
             }
             if (mt + 1 < CV_MT) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -216,13 +269,25 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
+        CV_STAMP(4)
         if (more) {
             __syncthreads();                                         // every wave is done with the staging area
-            put_input(xin, tid, xpre);
+            CV_STAMP(5)
+            put_input(xin, tid, st, xpre);
             __syncthreads();
+            CV_STAMP(6)
         }
     }
+#ifdef CV_PROF
+    if (tid == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) g_cvprof[blockIdx.x * 8 + k] = psum[k];
+#endif
 }
+
+#ifdef CV_PROF
+extern "C" int pnp_conv_prof_read(unsigned long long* out /* [1024][8] */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cvprof), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 // torch.nn.Conv2d weight [64 out][64 in][3][3] -> the kernel's fragment order: element e of lane (i, kh) of group G = tap * 8 + g,
 // N tile nt is W[out = 32 nt + i][in = 8 g + 4 kh + e][ky][kx], tap = 3 ky + kx  (v_mfma_f32_32x32x2_f32: lane l supplies
@@ -264,6 +329,7 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, con
     a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;        // one image must fit a signed 32-bit buffer offset (8 M pixels)
     static int cus[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
