@@ -203,7 +203,15 @@ int pnp_conv3x3_c64_nhwc(void* hip_stream, const float* x_dev, const float* w_pa
 /* w_oihw_dev: a torch.nn.Conv2d(64, 64, 3) weight, [64 out][64 in][3][3] contiguous -> w_packed_dev (36 864 floats).  Once
  * per model (again after the weights change). */
 int pnp_conv3x3_c64_pack(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev);
-/* [n][64][H][W] <-> [n][H][W][64] (to_nhwc = 1 / 0) for the stacks' first and last layers, which stay in PyTorch. */
+/* First and last layer of the plain stacks (models/network_dncnn.py:52-62, models/network_ffdnet.py:50-56), direct convolutions:
+ *   head: x [n][cin][H][W] (NCHW, 1 <= cin <= 8), w a torch Conv2d(cin, 64, 3) weight [64][cin][3][3] -> y [n][H][W][64] (NHWC), + bias, ReLU
+ *   tail: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight [cout][64][3][3], 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias
+ * With them `Denoiser(backend='hip')` runs DnCNN / FDnCNN / FFDNet without a MIOpen call.  New in ABI 8. */
+int pnp_conv3x3_head_nhwc(void* hip_stream, const float* x_nchw_dev, const float* w_oihw_dev, const float* bias_dev,
+                          float* y_nhwc_dev, int n, int cin, int H, int W, int relu);
+int pnp_conv3x3_tail_nchw(void* hip_stream, const float* x_nhwc_dev, const float* w_oihw_dev, const float* bias_dev,
+                          float* y_nchw_dev, int n, int cout, int H, int W);
+/* [n][64][H][W] <-> [n][H][W][64] (to_nhwc = 1 / 0): hand-over between PyTorch layers (NCHW) and the kernels above. */
 int pnp_relayout_c64(void* hip_stream, const float* in_dev, float* out_dev, int n, int H, int W, int to_nhwc);
 
 /* ---- timing on the ctx stream (HIP events) ------------------------------------------------ */

@@ -897,6 +897,18 @@ int pnp_conv3x3_c64_pack(void* stream, const float* w_oihw, float* w_packed) {
     HIPCHK(launch_conv_pack_w((hipStream_t)stream, w_oihw, w_packed));
     return PNP_OK;
 }
+int pnp_conv3x3_head_nhwc(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int cin, int H, int W, int relu) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_head_nhwc: null pointer");
+    if (n < 1 || H < 1 || W < 1 || cin < 1 || cin > 8) return fail(PNP_E_ARG, "pnp_conv3x3_head_nhwc: n, H, W >= 1 and 1 <= cin <= 8 required");
+    HIPCHK(launch_conv3x3_head((hipStream_t)stream, x, w, bias, y, n, cin, H, W, relu));
+    return PNP_OK;
+}
+int pnp_conv3x3_tail_nchw(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int cout, int H, int W) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_tail_nchw: null pointer");
+    if (n < 1 || H < 1 || W < 1 || cout < 1 || cout > 4) return fail(PNP_E_ARG, "pnp_conv3x3_tail_nchw: n, H, W >= 1 and 1 <= cout <= 4 required");
+    HIPCHK(launch_conv3x3_tail((hipStream_t)stream, x, w, bias, y, n, cout, H, W));
+    return PNP_OK;
+}
 int pnp_relayout_c64(void* stream, const float* in, float* out, int n, int H, int W, int to_nhwc) {
     if (!in || !out || in == out) return fail(PNP_E_ARG, "pnp_relayout_c64: null or aliased pointers");
     if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_relayout_c64: n, H, W must be >= 1");

@@ -78,6 +78,10 @@ hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw /*[64][64][3][3
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
                               float* y, int n, int H, int W, int relu);
 hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc);
+hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
+                               int n, int cin, int H, int W, int relu);
+hipError_t launch_conv3x3_tail(hipStream_t s, const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+                               int n, int cout, int H, int W);
 
 // How the fused loops are scheduled (scheduling only: results are bit-identical for every setting).
 struct FusedSchedule {

@@ -357,4 +357,186 @@ hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, 
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// First and last layer of the plain stacks (models/network_dncnn.py:52-62, models/network_ffdnet.py:50-56): few input or
+// few output channels -- no matrix-core shape, and bound by the 64-channel tensor they write or read (268 MB at 64 images of
+// 128 x 128).  Direct convolutions on the vector units, one 256-thread workgroup per 8 x 16 pixel tile, 16 lanes per group of
+// 8 consecutive pixels.  With them `Denoiser(backend='hip')` runs DnCNN / FDnCNN / FFDNet without a single MIOpen call.
+//   head  x [n][CIN][H][W] (NCHW, CIN <= 8)  ->  y [n][H][W][64] (NHWC), + bias, ReLU: lane cq of a group computes channels
+//         4 cq .. 4 cq + 3 of its 8 pixels (acc 32 registers); inputs and weights from LDS (broadcast reads)
+//   tail  x [n][H][W][64] (NHWC)  ->  y [n][COUT][H][W] (NCHW, COUT <= 4), + bias: lane cq holds input channels 4 cq .. + 3, the
+//         16 partial sums of a pixel meet by four DPP steps inside the lane row
+// ------------------------------------------------------------------------------------------
+constexpr int HD_MAXC = 8;
+struct HeadArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int n, cin, H, W, tiles_x, tiles_y, relu;
+};
+__global__ __launch_bounds__(256) void k_conv3x3_head(HeadArgs a) {
+    __shared__ float xin[HD_MAXC * CV_HY * CV_HX];                 // [ci][row 10][col 18]
+    __shared__ __attribute__((aligned(16))) float wl[HD_MAXC * 9 * CV_C];   // [ci * 9 + tap][64 out]
+    const int tid = threadIdx.x;
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int img = blockIdx.x / per_img, trem = blockIdx.x - img * per_img, ty = trem / a.tiles_x;
+    const int y0 = ty * CV_TY, x0 = (trem - ty * a.tiles_x) * CV_TX;
+    const size_t plane = (size_t)a.H * a.W;
+    const float* xb = a.x + (size_t)img * a.cin * plane;
+    for (int e = tid; e < a.cin * CV_HY * CV_HX; e += 256) {
+        const int ci = e / (CV_HY * CV_HX), p = e - ci * (CV_HY * CV_HX), r = p / CV_HX, c = p - r * CV_HX;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const float v = xb[(size_t)ci * plane + (size_t)(in ? gy : 0) * a.W + (in ? gx : 0)];
+        xin[e] = in ? v : 0.f;
+    }
+    for (int e = tid; e < a.cin * 9 * CV_C; e += 256) {            // w_oihw [64][cin][3][3] -> [ci * 9 + tap][out]
+        const int out = e & 63, k = e >> 6;                        // k = ci * 9 + tap
+        wl[e] = a.w[(size_t)out * a.cin * 9 + k];
+    }
+    __syncthreads();
+    const int cq = tid & 15, pg = tid >> 4, row = pg >> 1, col0 = (pg & 1) * 8;
+    f32x4 acc[8];
+    const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int px = 0; px < 8; ++px) acc[px] = b4;
+#pragma unroll 1
+    for (int ci = 0; ci < a.cin; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float in[10];
+            const float* rp = xin + (ci * CV_HY + row + ky) * CV_HX + col0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) in[k] = rp[k];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + (ci * 9 + ky * 3 + kx) * CV_C + 4 * cq);
+#pragma unroll
+                for (int px = 0; px < 8; ++px) {
+                    acc[px][0] = fmaf(in[px + kx], w4[0], acc[px][0]); acc[px][1] = fmaf(in[px + kx], w4[1], acc[px][1]);
+                    acc[px][2] = fmaf(in[px + kx], w4[2], acc[px][2]); acc[px][3] = fmaf(in[px + kx], w4[3], acc[px][3]);
+                }
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)img * plane * CV_C, a.H, a.W);
+    const int gy = y0 + row;
+#pragma unroll
+    for (int px = 0; px < 8; ++px) {
+        const int gx = x0 + col0 + px;
+        f32x4 v = acc[px];
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const int off = (gx < a.W) ? (gy * a.W + gx) * (CV_C * 4) + cq * 16 : -16;        // rows below the image: out of range, dropped
+        const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, off, 0, 0);
+    }
+}
+
+constexpr int TL_MAXC = 4;
+struct TailArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int n, cout, H, W, tiles_x, tiles_y;
+};
+__device__ __forceinline__ float row16_sum(float v) {             // sum over the 16 lanes of a DPP row, in every lane
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141 /* row_half_mirror */, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140 /* row_mirror */, 0xF, 0xF, true));
+    return v;
+}
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv3x3_tail(TailArgs a) {
+    __shared__ __attribute__((aligned(16))) float xin[CV_HY * CV_HX * CV_PS];
+    __shared__ __attribute__((aligned(16))) float wl[9 * COUT * CV_C];      // [tap][co][64 in]
+    const int tid = threadIdx.x;
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int img = blockIdx.x / per_img, trem = blockIdx.x - img * per_img, ty = trem / a.tiles_x;
+    const int y0 = ty * CV_TY, x0 = (trem - ty * a.tiles_x) * CV_TX;
+    const size_t plane = (size_t)a.H * a.W;
+    {
+        const __amdgpu_buffer_rsrc_t rs = image_rsrc(a.x + (size_t)img * plane * CV_C, a.H, a.W);
+        const int origin = ((y0 - 1) * a.W + (x0 - 1)) * (CV_C * 4);
+#pragma unroll
+        for (int u = 0; u < CV_XU; ++u) {
+            const int idx = tid + 256 * u, p = idx >> 4, cq = idx & 15, r = p / CV_HX, c = p - r * CV_HX;
+            const int gx = x0 - 1 + c;
+            const bool any = idx < CV_HY * CV_HX * 16;
+            const int off = (any && gx >= 0 && gx < a.W) ? origin + (r * a.W + c) * (CV_C * 4) + cq * 16 : -16;
+            const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            if (any) *reinterpret_cast<f32x4*>(xin + p * CV_PS + cq * 4) = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+        }
+    }
+    for (int e = tid; e < 9 * COUT * CV_C; e += 256) {             // w_oihw [cout][64][3][3] -> [tap][co][in]
+        const int in = e & 63, co = (e >> 6) % COUT, tap = e / (64 * COUT);
+        wl[e] = a.w[((size_t)co * 64 + in) * 9 + tap];
+    }
+    __syncthreads();
+    const int cq = tid & 15, pg = tid >> 4, row = pg >> 1, col0 = (pg & 1) * 8;
+    float acc[8][COUT];
+#pragma unroll
+    for (int px = 0; px < 8; ++px)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[px][co] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        f32x4 in[10];
+        const float* rp = xin + ((row + ky) * CV_HX + col0) * CV_PS + cq * 4;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) in[k] = *reinterpret_cast<const f32x4*>(rp + k * CV_PS);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + ((ky * 3 + kx) * COUT + co) * CV_C + cq * 4);
+#pragma unroll
+                for (int px = 0; px < 8; ++px) {
+                    const f32x4 v = in[px + kx];
+                    acc[px][co] = fmaf(v[3], w4[3], fmaf(v[2], w4[2], fmaf(v[1], w4[1], fmaf(v[0], w4[0], acc[px][co]))));
+                }
+            }
+        }
+    }
+    // the 16 lanes of a group hold partial sums over their four input channels: total them, lane px (< 8) keeps pixel px
+    const int gy = y0 + row, gx = x0 + col0 + cq;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float mine = 0.f;
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+            const float s = row16_sum(acc[px][co]);
+            mine = (cq == px) ? s : mine;
+        }
+        if (cq < 8 && gy < a.H && gx < a.W)
+            a.y[((size_t)img * COUT + co) * plane + (size_t)gy * a.W + gx] = mine + (a.bias ? a.bias[co] : 0.f);
+    }
+}
+
+hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
+                               int n, int cin, int H, int W, int relu) {
+    if (cin < 1 || cin > HD_MAXC || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    HeadArgs a;
+    a.x = x_nchw; a.w = w_oihw; a.bias = bias; a.y = y_nhwc; a.n = n; a.cin = cin; a.H = H; a.W = W; a.relu = relu;
+    a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
+    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv3x3_head, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_conv3x3_tail(hipStream_t s, const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+                               int n, int cout, int H, int W) {
+    if (cout < 1 || cout > TL_MAXC || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    TailArgs a;
+    a.x = x_nhwc; a.w = w_oihw; a.bias = bias; a.y = y_nchw; a.n = n; a.cout = cout; a.H = H; a.W = W;
+    a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
+    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)tiles), block(256);
+    switch (cout) {
+        case 1: hipLaunchKernelGGL(k_conv3x3_tail<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(k_conv3x3_tail<2>, grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(k_conv3x3_tail<3>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(k_conv3x3_tail<4>, grid, block, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
 }  // namespace pnp

@@ -66,21 +66,49 @@ def _hip_weights(seq, k, conv, L, stream):
     return hit[1]
 
 
+def _hip_oihw(seq, k, conv):
+    """conv.weight as an [out][in][3][3]-contiguous tensor (the parameter may be in channels_last format), cached like the packed
+    weights and rebuilt when the parameter changes."""
+    cache = seq.__dict__.setdefault('_pnp_hip_oihw', {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    hit = cache.get(k)
+    if hit is None or hit[0] != key:
+        cache[k] = hit = (key, w.detach().contiguous(memory_format=torch.contiguous_format).clone())
+    return hit[1]
+
+
+def _plain3x3(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros')
+
+
 def hip_stack_forward(seq, x):
-    """`seq(x)` for a [Conv3x3, ReLU] * (nb - 1) + Conv3x3 stack with its eligible 64 -> 64 layers on the HIP kernel.
-    Raises if the library or a GPU tensor is missing: no silent fallback to another device; layers the kernel does not cover
-    (other channel counts, dilations) run in PyTorch inside the same call."""
+    """`seq(x)` for a [Conv3x3, ReLU] * (nb - 1) + Conv3x3 stack on libpnpmri.so's convolution kernels: 64 -> 64 layers on the
+    fp32-MFMA implicit GEMM, a first layer with <= 8 input channels and a last layer with <= 4 output channels on the direct
+    kernels -- DnCNN / FDnCNN / FFDNet then run without a MIOpen call.  Raises if the library or a GPU tensor is missing: no
+    silent fallback to another device; layers the kernels do not cover (other channel counts, dilations) run in PyTorch
+    inside the same call."""
     import ctypes as C
     from . import _lib
     if not (x.is_cuda and x.dtype == torch.float32):
         raise RuntimeError("Denoiser(backend='hip') needs float32 CUDA tensors")
     L = _lib.lib()
     stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     mods = list(seq)
     h, nhwc, k = x, None, 0                                    # h: NCHW tensor, or nhwc: [n][H][W][64] between HIP layers
     while k < len(mods):
         m = mods[k]
         relu = k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU)
+        if nhwc is None and _plain3x3(m) and m.in_channels <= 8 and m.out_channels == 64:              # head
+            hc = h.contiguous()
+            n, _, H, W = hc.shape
+            nhwc = torch.empty((n, H, W, 64), dtype=torch.float32, device=h.device)
+            _lib.check(L.pnp_conv3x3_head_nhwc(stream, ptr(hc), ptr(_hip_oihw(seq, k, m)), ptr(m.bias), ptr(nhwc),
+                                               n, m.in_channels, H, W, 1 if relu else 0))
+            k += 2 if relu else 1
+            continue
         if _hip_body_ok(m):
             if nhwc is None:
                 hp = h.permute(0, 2, 3, 1)
@@ -88,21 +116,38 @@ def hip_stack_forward(seq, x):
                     nhwc = hp
                 else:
                     nhwc = torch.empty(hp.shape, dtype=h.dtype, device=h.device)
-                    _lib.check(L.pnp_relayout_c64(stream, C.c_void_p(h.contiguous().data_ptr()), C.c_void_p(nhwc.data_ptr()),
-                                                  h.shape[0], h.shape[2], h.shape[3], 1))
+                    _lib.check(L.pnp_relayout_c64(stream, ptr(h.contiguous()), ptr(nhwc), h.shape[0], h.shape[2], h.shape[3], 1))
             n, H, W, _ = nhwc.shape
             out = torch.empty_like(nhwc)
-            bias = None if m.bias is None else C.c_void_p(m.bias.data_ptr())
-            _lib.check(L.pnp_conv3x3_c64_nhwc(stream, C.c_void_p(nhwc.data_ptr()), C.c_void_p(_hip_weights(seq, k, m, L, stream).data_ptr()), bias,
-                                              None, C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0))
+            _lib.check(L.pnp_conv3x3_c64_nhwc(stream, ptr(nhwc), ptr(_hip_weights(seq, k, m, L, stream)), ptr(m.bias), None, ptr(out),
+                                              n, H, W, 1 if relu else 0))
             nhwc = out
             k += 2 if relu else 1
+            continue
+        if nhwc is not None and _plain3x3(m) and m.in_channels == 64 and m.out_channels <= 4 and not relu:   # tail
+            n, H, W, _ = nhwc.shape
+            h = torch.empty((n, m.out_channels, H, W), dtype=torch.float32, device=nhwc.device)
+            _lib.check(L.pnp_conv3x3_tail_nchw(stream, ptr(nhwc), ptr(_hip_oihw(seq, k, m)), ptr(m.bias), ptr(h),
+                                               n, m.out_channels, H, W))
+            nhwc = None
+            k += 1
             continue
         if nhwc is not None:
             h, nhwc = nhwc.permute(0, 3, 1, 2), None           # a channels_last NCHW view: PyTorch takes it as it is
         h = m(h)
         k += 1
     return h if nhwc is None else nhwc.permute(0, 3, 1, 2)
+
+
+def hip_covers_stack(seq):
+    """True when every convolution of the stack runs on libpnpmri.so under backend 'hip' (head, 64 -> 64 body, tail): such a
+    forward makes no MIOpen call at all."""
+    convs = [m for m in seq if isinstance(m, nn.Conv2d)]
+    if len(convs) < 2 or any(not isinstance(m, (nn.Conv2d, nn.ReLU)) for m in seq):
+        return False
+    head, tail = convs[0], convs[-1]
+    return (_plain3x3(head) and head.in_channels <= 8 and head.out_channels == 64 and _plain3x3(tail) and tail.in_channels == 64
+            and tail.out_channels <= 4 and all(_hip_body_ok(m) for m in convs[1:-1]))
 
 
 class _PlainStack(nn.Module):
@@ -460,6 +505,8 @@ class Denoiser:
         if out is None:
             out = torch.empty_like(x)
         find = (min(B, self.cnn_batch) >= 16 and x.is_cuda) if self.miopen_find == 'auto' else bool(self.miopen_find)
+        if self.backend == 'hip' and isinstance(self.model, _PlainStack) and hip_covers_stack(self.model.model):
+            find = False                      # no MIOpen call in this forward: the process-global flag is left alone
         cd = torch.backends.cudnn
         before = cd.benchmark
         cd.benchmark = bool(find or before)

@@ -65,6 +65,61 @@ def test_conv3x3_c64_against_pytorch(env, n, H, W, variant):
     assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.double(), w.double(), padding=1)) <= 1e-6
 
 
+@pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 16, 16), (2, 5, 23), (1, 1, 1), (4, 128, 128)])
+def test_head_and_tail_layers_against_pytorch(env, n, H, W):
+    """the direct kernels of the stacks' first (cin <= 8 -> 64, NCHW -> NHWC, + bias + ReLU) and last layer (64 -> cout <= 4, NHWC ->
+    NCHW, + bias): every channel count the reference's models use (DnCNN 1, FDnCNN 2, FFDNet 5 in; 1 and 4 out) and the rest"""
+    torch, F, L, lib = env['torch'], env['F'], env['L'], env['lib']
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    g = torch.Generator(device='cuda').manual_seed(7 * n + H + W)
+    for cin in (1, 2, 5, 8):
+        x = torch.randn(n, cin, H, W, device='cuda', generator=g)
+        w = torch.randn(64, cin, 3, 3, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(64, device='cuda', generator=g) * 0.1
+        for relu, bias in ((1, b), (0, None)):
+            y = torch.empty(n, H, W, 64, device='cuda')
+            lib.check(L.pnp_conv3x3_head_nhwc(s, p(x), p(w), p(bias), p(y), n, cin, H, W, relu))
+            ref = F.conv2d(x.double(), w.double(), None if bias is None else bias.double(), padding=1)
+            ref = F.relu(ref) if relu else ref
+            assert _rel(y.permute(0, 3, 1, 2), ref) <= 2e-6, (cin, relu)
+    xn = torch.randn(n, H, W, 64, device='cuda', generator=g)
+    for cout in (1, 2, 3, 4):
+        w = torch.randn(cout, 64, 3, 3, device='cuda', generator=g) * (2.0 / 576) ** 0.5
+        b = torch.randn(cout, device='cuda', generator=g) * 0.1
+        for bias in (b, None):
+            y = torch.empty(n, cout, H, W, device='cuda')
+            lib.check(L.pnp_conv3x3_tail_nchw(s, p(xn), p(w), p(bias), p(y), n, cout, H, W))
+            ref = F.conv2d(xn.permute(0, 3, 1, 2).double(), w.double(), None if bias is None else bias.double(), padding=1)
+            assert _rel(y, ref) <= 2e-6, cout
+    with pytest.raises(lib.PnpError):
+        lib.check(L.pnp_conv3x3_head_nhwc(s, p(xn), p(xn), None, p(xn), n, 9, H, W, 0))       # cin > 8
+    with pytest.raises(lib.PnpError):
+        lib.check(L.pnp_conv3x3_tail_nchw(s, p(xn), p(xn), None, p(xn), n, 5, H, W))          # cout > 4
+
+
+def test_hip_backend_of_a_plain_stack_makes_no_miopen_call(env):
+    """FFDNet with backend='hip': head, 13 body layers and tail all run on libpnpmri.so -- torch.nn.functional.conv2d is never
+    reached (checked by making it raise for the duration of the call)."""
+    torch, D, F = env['torch'], env['D'], env['F']
+    net, nlm, _ = D.build('ffdnet_gray')
+    net.load_state_dict(D.seeded_state_dict(net, 3))
+    den = D.Denoiser('ffdnet_gray', net.eval(), nlm, backend='hip', miopen_find=False).to('cuda')
+    x = torch.rand(2, 1, 64, 64, device='cuda')
+    ref = D.Denoiser('ffdnet_gray', net, nlm, backend='torch', miopen_find=False)(x, 0).clone()
+    net.backend = 'hip'
+    orig = torch.nn.Conv2d.forward
+
+    def boom(self, inp):
+        raise AssertionError('a PyTorch convolution was called')
+    torch.nn.Conv2d.forward = boom
+    try:
+        out = den(x, 0)
+    finally:
+        torch.nn.Conv2d.forward = orig
+    assert _rel(out, ref) <= 1e-5
+
+
 def test_relayout_round_trip_and_argument_errors(env):
     torch, L, lib = env['torch'], env['L'], env['lib']
     x = torch.randn(3, 64, 37, 21, device='cuda')

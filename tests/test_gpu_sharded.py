@@ -22,7 +22,7 @@ def _problem():
     return masks, y, mid
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, precision='f32'):
     import torch.distributed as dist
     import pnp_admm_cnc_mri_amd as P
     from pnp_admm_cnc_mri_amd import sharding
@@ -32,7 +32,7 @@ def _worker(rank, world, port, q):
     try:
         masks, y, mid = _problem()
         solver = functools.partial(P.ADMM_CNC, device=0, results='/tmp/pnp_sharded_results_%d' % rank)
-        x = sharding.solve_sharded(solver, masks, None, y=y, mask_id=mid, **P.PRESETS['ADMM_CNC'])
+        x = sharding.solve_sharded(solver, masks, None, y=y, mask_id=mid, precision=precision, **P.PRESETS['ADMM_CNC'])
         if rank == 0:
             q.put(x)
         dist.barrier()
@@ -40,7 +40,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process():
+@pytest.mark.parametrize('precision', ['f32', 'f64'])
+def test_two_ranks_equal_one_process(precision):
     import torch.multiprocessing as mp
     import pnp_admm_cnc_mri_amd as P
     s = socket.socket()
@@ -49,7 +50,7 @@ def test_two_ranks_equal_one_process():
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, precision)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -57,8 +58,10 @@ def test_two_ranks_equal_one_process():
         p.join(timeout=300)
         assert p.exitcode == 0
     masks, y, mid = _problem()
-    out = P.ADMM_CNC(masks, None, y=y, mask_id=mid, results='/tmp/pnp_sharded_results_ref', **P.PRESETS['ADMM_CNC'])
-    ref = np.stack([out[b].astype(np.float32) for b in range(len(y))])
+    out = P.ADMM_CNC(masks, None, y=y, mask_id=mid, results='/tmp/pnp_sharded_results_ref', precision=precision, **P.PRESETS['ADMM_CNC'])
+    real = np.float64 if precision == 'f64' else np.float32             # the gather keeps the solver's precision
+    ref = np.stack([out[b].astype(real) for b in range(len(y))])
+    assert got.dtype == real
     # rank 0 holds slices 0..3 (pairs (0,1),(2,3)), rank 1 slices 4..6; in the single process slice 4
     # is paired with 5 and 6 is alone in both cases, so pairing is identical -> bit-identical
     assert got.shape == ref.shape and np.array_equal(got, ref)
