@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--mask', type=int, default=0, help='0 Q_Random30, 1 Q_Radial30, 2 Q_Cartesian30 (k of S4:199)')
     ap.add_argument('--testset', default=None)
     ap.add_argument('--results', default='results')
+    ap.add_argument('--precision', choices=['f32', 'f64'], default='f32',
+                    help="f64 = the reference's own float64 arithmetic on the device (meets 1e-5 on the committed presets)")
     # the reference's own flags (S4:21-29); unset = committed presets
     for f, t in (('alpha', float), ('iter_num', int), ('lambda1', float), ('reo', float), ('b', float)):
         ap.add_argument('--' + f, type=t, default=None)
@@ -38,7 +40,7 @@ def main():
         name, ['Q_Random30', 'Q_Radial30', 'Q_Cartesian30'][a.mask]))
     fn = P.ADMM_L1 if a.solver == 'l1' else P.ADMM_CNC
     out, info = fn(mask[a.mask], noises, testsets=testsets, testset_name=testset, results=a.results,
-                   return_info=True, **opts)
+                   return_info=True, precision=a.precision, **opts)
     for k in ('psnr', 'ssim', 're'):
         print(k, ['%.4f' % v for v in info[k]])
 
