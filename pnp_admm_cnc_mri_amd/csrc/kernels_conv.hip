@@ -47,6 +47,12 @@ constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packe
 #ifndef CV_BD_N
 #define CV_BD_N 3
 #endif
+#ifndef CV_WPS
+#define CV_WPS 2                               // workgroups per compute unit = waves per SIMD (MT = 1): 2 or 3
+#endif
+#ifndef CV_RING
+#define CV_RING 8                              // register slots of the weight-fragment ring (a power of two > CV_BD_N, dividing 8)
+#endif
 constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of 8 register slots)
 
 #ifdef CV_PROF
@@ -132,7 +138,7 @@ __device__ __forceinline__ void put_input(float* xin, int tid, const Staging& st
 //     147 KiB for every workgroup (L2-resident), requested CV_BD groups ahead of their use -- an endless periodic stream
 //     (group 72 of a tile is group 0 of the next).  With the weight slices staged through LDS a workgroup needed a barrier
 //     per tap: 0.78 of the matrix peak, the matrix pipe idle a fifth of the time; without, three barriers per tile.
-__global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c64(ConvArgs a, int ntiles) {
+__global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3x3_c64(ConvArgs a, int ntiles) {
     __shared__ __attribute__((aligned(16))) float xin[CV_XIN];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
     fetch_input(a, tile_pos(a, tile), st, xpre);
     put_input(xin, tid, st, xpre);
     // weight fragments of the first CV_BD groups; ring slot = G % 8 (8 groups per tap: the slot of a group is static)
-    f32x4 bq0[8], bq1[8];
+    f32x4 bq0[CV_RING], bq1[CV_RING];
 #pragma unroll
     for (int d = 0; d < CV_BD; ++d) { bq0[d] = wl[(2 * d) * 64]; bq1[d] = wl[(2 * d + 1) * 64]; }
     __syncthreads();
@@ -198,16 +204,16 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? 2 : 1)) void k_conv3x3_c6
                 {
                     int G = gpre + g;
                     G = G >= CV_GROUPS ? G - CV_GROUPS : G;
-                    bq0[(g + CV_BD) & 7] = wl[(2 * G) * 64];
-                    bq1[(g + CV_BD) & 7] = wl[(2 * G + 1) * 64];
+                    bq0[(g + CV_BD) & (CV_RING - 1)] = wl[(2 * G) * 64];
+                    bq1[(g + CV_BD) & (CV_RING - 1)] = wl[(2 * G + 1) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
                     for (int mt = 0; mt < CV_MT; ++mt) {
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt][e], bq0[g][e], acc0[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt][e], bq1[g][e], acc1[mt], 0, 0, 0);
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt][e], bq0[g & (CV_RING - 1)][e], acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt][e], bq1[g & (CV_RING - 1)][e], acc1[mt], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -339,7 +345,7 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, con
         cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     // persistent workgroups, two per compute unit (77 KiB of LDS each); every workgroup's loop ends: tile < ntiles
-    const long long resident = (CV_MT == 1 ? 2LL : 1LL) * cus[dev];
+    const long long resident = (CV_MT == 1 ? (long long)CV_WPS : 1LL) * cus[dev];
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     hipLaunchKernelGGL(k_conv3x3_c64, dim3(grid), dim3(CV_THREADS), 0, s, a, (int)tiles);
     return hipGetLastError();
