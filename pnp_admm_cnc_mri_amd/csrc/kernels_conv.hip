@@ -1,27 +1,34 @@
 // Optional HIP backend of the denoisers' plain convolution stacks (FFDNet, DnCNN: models/network_ffdnet.py:58-73,
-// models/network_dncnn.py:36-67, both built from models/basicblock.py:63-100 `conv(..., mode='CR')`): one kernel,
+// models/network_dncnn.py:36-67, both built from models/basicblock.py:63-100 `conv(..., mode='CR')`) and of DRUNet's
+// 64-channel residual blocks (models/basicblock.py:213-225).  The body layer,
 //
-//     y = relu?( conv3x3(x, w) + bias ),   64 -> 64 channels, stride 1, zero padding 1, float32,
+//     y = relu?( conv3x3(x, w) + bias + skip ),   64 -> 64 channels, stride 1, zero padding 1, float32,
 //
-// as an implicit GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact f32 fma chains at the f32 vector
-// peak, 64 FLOP/clk/SIMD -- MI355X has no TF32-like shortcut).  The north star keeps the CNN forward in PyTorch-ROCm; this
-// is the opt-in `Denoiser(backend='hip')` for the 64-channel body layers, where configs 3-5 spend 99.8 % of their time.
+// is an implicit GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact f32 fma chains at the f32 vector
+// peak, 64 FLOP/clk/SIMD -- MI355X has no TF32-like shortcut); the stacks' first (<= 8 -> 64) and last (64 -> <= 4) layers are
+// direct kernels at the end of this file.  The north star keeps the CNN forward in PyTorch-ROCm: this is the opt-in
+// `Denoiser(backend='hip')`, for the layers where configs 3-5 spend 99.8 % of their time.  DESIGN.md 4.7; every structure
+// tried with its time: profiles/conv_variants_r04.txt.
 //
 //   layout   activations NHWC ([image][row][col][64 channels]): the K direction of the GEMM (input channels of one tap) is
-//            contiguous, a pixel is 256 bytes; weights packed once per model into fragment order by pnp_conv3x3_c64_pack
+//            contiguous, a pixel is 256 bytes; weights packed once per model into MFMA-fragment order by pnp_conv3x3_c64_pack
 //   tile     one 256-thread workgroup = 8 x 16 output pixels x 64 output channels of one image; wave w owns rows 2w, 2w+1
 //            (32 pixels = the M of one MFMA) x both halves of the output channels: 2 accumulator tiles = 32 VGPRs.
-//            45 KiB of LDS, 2 waves per SIMD by registers: TWO workgroups per compute unit, one's staging and epilogue run
-//            under the other's MFMAs (a 16 x 16 tile with one 512-thread workgroup per unit: 0.70 of the matrix peak)
-//   K loop   9 taps x 64 input channels.  The 10 x 18 x 64 input tile (halo included, zero-filled outside the image) stays in
-//            LDS for the whole tile; the weights stream from L2 straight into registers in MFMA-fragment order (k_conv_pack_w),
-//            three operand groups ahead of their use -- no weight staging, no barrier inside a tile's 576 MFMAs per wave
-//   operands one ds_read_b128 per lane = four consecutive input channels = the A (or B) operand of FOUR MFMA steps: lane
+//            48 KiB of LDS, 172 VGPRs: TWO workgroups per compute unit, one's staging and epilogue run under the other's
+//            MFMAs (a 16 x 16 tile with one 512-thread workgroup per unit: 0.70 of the matrix peak)
+//   K loop   9 taps x 64 input channels.  The 10 x 18 x 64 input tile (halo included, zeros outside the image) stays in LDS
+//            for the whole tile, 272 bytes per pixel (the 16 lanes a b128 read serves per cycle -- consecutive pixels, same
+//            channels -- start 4 banks apart; the eight operand groups of a tap are immediate offsets of one address); the
+//            weights stream from L2 straight into registers, three operand groups ahead of their use -- no weight staging,
+//            no barrier inside a tile's 576 MFMAs per accumulator
+//   operands one 16-byte read per lane = four consecutive input channels = the A (or B) operand of FOUR MFMA steps: lane
 //            (i, kh) of v_mfma_f32_32x32x2_f32 supplies A[i][k = kh], so lane half kh reads channels 8 g + 4 kh .. + 3 of
 //            group g and step e = 0..3 pairs channel 8 g + e with 8 g + 4 + e -- the same on the weight side, so the K order
-//            is consistent.  LDS images are XOR-swizzled on the 16-byte chunk index (chunk ^ (pixel & 15)): the 16 lanes a
-//            b128 access serves per cycle hit 16 distinct 4-bank groups.
-//   epilogue bias + ReLU on the accumulators, 128-byte row segments per (pixel, half of the channels)
+//            is consistent
+//   persist  512 workgroups loop over the tiles; the next tile's input is fetched into registers under this tile's MFMAs
+//            (buffer loads whose out-of-image pixels fall outside the descriptor's range and return zeros: no branches)
+//   epilogue bias = the accumulators' initial value; the wave's 32 x 64 outputs go through 8 KiB of the idle input tile and
+//            leave as eight 16-byte stores per lane (a 256-byte pixel per 16 lanes); skip and ReLU join there
 #include "internal.h"
 #include <hip/hip_runtime.h>
 
@@ -53,7 +60,7 @@ constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packe
 #ifndef CV_RING
 #define CV_RING 8                              // register slots of the weight-fragment ring (a power of two > CV_BD_N, dividing 8)
 #endif
-constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of 8 register slots)
+constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of CV_RING register slots)
 
 #ifdef CV_PROF
 // diagnostic build (profiles/variants.sh build kernels_conv.hip prof "-DCV_PROF"): shader-clock sums per phase, wave 0 of every workgroup
