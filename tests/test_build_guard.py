@@ -24,7 +24,7 @@ from conftest import ROOT
 
 CSRC = os.path.join(ROOT, 'pnp_admm_cnc_mri_amd', 'csrc')
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'api.hip']
+SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'kernels_conv.hip', 'api.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off']     # = csrc/Makefile CXXFLAGS
 
 import importlib.util
@@ -99,6 +99,23 @@ def test_512_column_kernel_register_budget(asm):
 
 
 
+
+
+def test_conv_kernel_keeps_two_workgroups_per_compute_unit(asm):
+    """k_conv3x3_c64 counts on TWO persistent workgroups per compute unit -- one's staging and epilogue under
+    the other's MFMAs: no scratch, at most 256 VGPRs + AGPRs (2 waves per SIMD), at most 80 KiB of LDS; its MFMAs are the fp32
+    32x32x2 form; the generic blend kernel stays at three workgroups per unit (<= 168 VGPRs, 0 scratch)."""
+    ks = kernels_of(asm['kernels_conv.hip'])
+    body = [k for n, k in ks.items() if 'k_conv3x3_c64' in n]
+    assert len(body) == 1, sorted(ks)
+    i = body[0]['info']
+    assert i['ScratchSize'] == 0 and i['NumVgprs'] + i['NumAgprs'] <= 256 and i['LDSByteSize'] <= 80 * 1024, i
+    mf = [x for x in body[0]['body'] if x.startswith('v_mfma')]
+    assert len(mf) == 64 and all(x.startswith('v_mfma_f32_32x32x2_f32') for x in mf), len(mf)      # 8 groups x 4 steps x 2 accumulators, taps looped
+    for n, k in ks.items():
+        assert k['info']['ScratchSize'] == 0, (n, k['info'])
+    blend = [k for n, k in kernels_of(asm['kernels_generic.hip']).items() if 'k_cols16ILb1ELi1ELb1E' in n]
+    assert len(blend) == 1 and blend[0]['info']['NumVgprs'] <= 168 and blend[0]['info']['ScratchSize'] == 0, blend[0]['info']
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():
