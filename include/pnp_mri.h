@@ -194,12 +194,13 @@ int pnp_ssim_f64(pnp_ctx* ctx, const double* x_dev, const uint8_t* gt, int gt_on
  * for the 64 -> 64 channel conv3x3 (+ bias, + ReLU) body layers of FFDNet / DnCNN / FDnCNN (models/network_ffdnet.py:58-73,
  * models/network_dncnn.py:36-67, models/basicblock.py:63-100 mode 'CR'), where configs 3-5 spend 99.8 % of their time:
  * an implicit GEMM on the fp32 matrix cores (exact f32 fma chains).  No ctx: caller-owned device tensors, any HIP stream.
- *   y = relu?( conv3x3(x, w) + bias + skip ),  stride 1, zero padding 1 (torch.nn.Conv2d(64, 64, 3, 1, 1))
+ *   y = relu?( conv3x3(x, w) + bias + skip ),  stride 1, dilation d = 1..4, zero padding d (torch.nn.Conv2d(64, 64, 3, 1, d, dilation=d):
+ *   d = 1 the plain stacks and DRUNet, d = 2..4 IRCNN's dilated layers, models/network_dncnn.py:87-101)
  *   x, y, skip: [n][H][W][64] float32 (NHWC); w_packed: 36 864 floats written by pnp_conv3x3_c64_pack (the kernel streams
  *   its weights from L2 in matrix-core fragment order); bias [64] or NULL; skip NULL or a tensor of y's shape added before the
  *   ReLU; y must alias neither x nor skip.  New in ABI 8. */
 int pnp_conv3x3_c64_nhwc(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
-                         const float* skip_dev, float* y_dev, int n, int H, int W, int relu);
+                         const float* skip_dev, float* y_dev, int n, int H, int W, int relu, int dilation);
 /* w_oihw_dev: a torch.nn.Conv2d(64, 64, 3) weight, [64 out][64 in][3][3] contiguous -> w_packed_dev (36 864 floats).  Once
  * per model (again after the weights change). */
 int pnp_conv3x3_c64_pack(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev);

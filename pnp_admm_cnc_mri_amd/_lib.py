@@ -63,7 +63,7 @@ SIGNATURES = {
     'pnp_metrics_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p, c_double_p]),
     'pnp_ssim_f64': (C.c_int, [ctx_p, _vp, _vp, C.c_int, c_double_p]),
     'pnp_prepare_loops': (C.c_int, [ctx_p]),
-    'pnp_conv3x3_c64_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv3x3_c64_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_c64_pack': (C.c_int, [_vp, _vp, _vp]),
     'pnp_conv3x3_head_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_tail_nchw': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),

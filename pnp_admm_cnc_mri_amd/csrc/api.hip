@@ -887,11 +887,12 @@ int pnp_is_f64(pnp_ctx* c) { return (c && c->f64) ? 1 : 0; }
 
 /* ---- optional HIP backend of the denoisers' 64-channel body layers (no ctx: caller-owned device tensors) ---- */
 int pnp_conv3x3_c64_nhwc(void* stream, const float* x, const float* w, const float* bias, const float* skip, float* y,
-                         int n, int H, int W, int relu) {
+                         int n, int H, int W, int relu, int dilation) {
     if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: null pointer");
     if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: n, H, W must be >= 1");
     if (x == y || skip == y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: y must not alias x or skip (tiles read their neighbours' halo)");
-    HIPCHK(launch_conv3x3_c64((hipStream_t)stream, x, w, bias, skip, y, n, H, W, relu));
+    if (dilation < 1 || dilation > 4) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc: dilation must be 1..4 (got %d)", dilation);
+    HIPCHK(launch_conv3x3_c64((hipStream_t)stream, x, w, bias, skip, y, n, H, W, relu, dilation));
     return PNP_OK;
 }
 int pnp_conv3x3_c64_pack(void* stream, const float* w_oihw, float* w_packed) {

@@ -76,7 +76,7 @@ hipError_t launch_widen(hipStream_t s, const float* in, double* out, size_t n); 
 // optional HIP backend of the denoisers' 64-channel conv3x3 body layers (kernels_conv.hip); activations NHWC float32
 hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw /*[64][64][3][3]*/, float* wfrag /*36 864 floats*/);
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
-                              float* y, int n, int H, int W, int relu);
+                              float* y, int n, int H, int W, int relu, int dilation /* 1..4 */);
 hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc);
 hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                                int n, int cin, int H, int W, int relu);

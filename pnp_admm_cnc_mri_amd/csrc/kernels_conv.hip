@@ -42,12 +42,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int CV_MT = CV_MT_N;                 // M tiles (of 32 pixels = 2 tile rows) per wave: 1 -> 8 x 16 tiles, two workgroups per unit; 2 -> 16 x 16, one
 constexpr int CV_TX = 16, CV_TY = 8 * CV_MT;   // output tile
-constexpr int CV_HX = CV_TX + 2, CV_HY = CV_TY + 2;      // with halo
 constexpr int CV_C = 64;                       // channels in and out
 constexpr int CV_PS = CV_C + 4;                // floats between consecutive pixels of the LDS tile: 272 bytes, so that the 16 lanes a b128
                                                // read serves per cycle (consecutive pixels, same channels) start 4 banks apart -- and the
                                                // eight operand groups of a tap are IMMEDIATE offsets of one address (no per-group VALU)
-constexpr int CV_XIN = CV_HY * CV_HX * CV_PS;  // floats of the input tile: 48 960 bytes (MT = 1)
 constexpr int CV_THREADS = 256;
 constexpr int CV_GROUPS = 9 * 8;               // operand groups per tile: 9 taps x 8 groups of 8 input channels
 constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packed weights (= 9 * 64 * 64)
@@ -60,6 +58,15 @@ constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packe
 #ifndef CV_RING
 #define CV_RING 8                              // register slots of the weight-fragment ring (a power of two > CV_BD_N, dividing 8)
 #endif
+// Tile geometry by dilation DIL (1: the plain stacks and DRUNet; 2..4: IRCNN's dilated layers, models/network_dncnn.py:87-101): the
+// halo is DIL pixels wide, the taps lie DIL pixels apart.  48 / 64 KiB of LDS at DIL 1 / 2 (two workgroups per compute unit), 82 /
+// 102 KiB at DIL 3 / 4 (one).
+template <int DIL> struct Geo {
+    static constexpr int HX = CV_TX + 2 * DIL, HY = CV_TY + 2 * DIL;                    // tile with halo
+    static constexpr int XIN = HY * HX * CV_PS;                                         // floats of the input tile
+    static constexpr int XU = (HY * HX * 16 + CV_THREADS - 1) / CV_THREADS;             // its 16-byte chunks per thread (12 at DIL 1)
+    static constexpr int WPS = (CV_MT == 1 && XIN * 4 <= 80 * 1024) ? CV_WPS : 1;       // workgroups per compute unit
+};
 constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of CV_RING register slots)
 
 #ifdef CV_PROF
@@ -90,21 +97,21 @@ __device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
     return q;
 }
 
-constexpr int CV_XU = (CV_HY * CV_HX * 16 + CV_THREADS - 1) / CV_THREADS;     // 16-byte chunks of the input tile per thread (12)
-
 // Per-thread constants of the input staging, computed ONCE: vector instructions issued beside the partner wave's MFMA
 // stream are slow and cost that stream issue slots (phase clocks, profiles/conv_variants_r04.txt), so everything that does not
 // depend on the tile is out of the loop.  Chunk u of thread tid is (tile pixel p = (tid + 256 u) >> 4, channels 4 cq ..).
-struct Staging {
-    int goff[CV_XU];     // byte offset of the chunk relative to the tile's first halo pixel (row y0 - 1, column x0 - 1), or < 0: none
-    int col[CV_XU];      // tile column of the pixel (0 .. 17): the only coordinate that needs a test (rows fall out of the buffer range)
-    int loff[CV_XU];     // float offset in the LDS tile
+template <int DIL> struct Staging {
+    int goff[Geo<DIL>::XU];     // byte offset of the chunk relative to the tile's first halo pixel (row y0 - DIL, column x0 - DIL), or < 0: none
+    int col[Geo<DIL>::XU];      // tile column of the pixel: the only coordinate that needs a test (rows fall out of the buffer range)
+    int loff[Geo<DIL>::XU];     // float offset in the LDS tile
 };
-__device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging& st) {
+template <int DIL>
+__device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging<DIL>& st) {
+    constexpr int HX = Geo<DIL>::HX, HY = Geo<DIL>::HY;
 #pragma unroll
-    for (int u = 0; u < CV_XU; ++u) {
-        const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15, r = p / CV_HX, c = p - r * CV_HX;
-        const bool any = idx < CV_HY * CV_HX * 16;
+    for (int u = 0; u < Geo<DIL>::XU; ++u) {
+        const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15, r = p / HX, c = p - r * HX;
+        const bool any = idx < HY * HX * 16;
         st.goff[u] = any ? (r * a.W + c) * (CV_C * 4) + cq * 16 : -1;
         st.col[u] = c;
         st.loff[u] = any ? p * CV_PS + cq * 4 : 0;
@@ -119,22 +126,24 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* base, int H, int W) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((unsigned)H * (unsigned)W * (CV_C * 4u)), 0x00020000);
 }
-__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, const Staging& st, f32x4 (&v)[CV_XU]) {
+template <int DIL>
+__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, const Staging<DIL>& st, f32x4 (&v)[Geo<DIL>::XU]) {
     const __amdgpu_buffer_rsrc_t rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
-    const int origin = ((q.y0 - 1) * a.W + (q.x0 - 1)) * (CV_C * 4);            // may be negative: such offsets are out of range as unsigned
-    const int xlo = 1 - q.x0, xhi = a.W + 1 - q.x0;                              // valid tile columns: xlo <= c < xhi
+    const int origin = ((q.y0 - DIL) * a.W + (q.x0 - DIL)) * (CV_C * 4);        // may be negative: such offsets are out of range as unsigned
+    const int xlo = DIL - q.x0, xhi = a.W + DIL - q.x0;                          // valid tile columns: xlo <= c < xhi
 #pragma unroll
-    for (int u = 0; u < CV_XU; ++u) {
+    for (int u = 0; u < Geo<DIL>::XU; ++u) {
         const bool in = st.goff[u] >= 0 && st.col[u] >= xlo && st.col[u] < xhi;
         const int off = in ? origin + st.goff[u] : -16;
         const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
     }
 }
-__device__ __forceinline__ void put_input(float* xin, int tid, const Staging& st, const f32x4 (&v)[CV_XU]) {
+template <int DIL>
+__device__ __forceinline__ void put_input(float* xin, int tid, const Staging<DIL>& st, const f32x4 (&v)[Geo<DIL>::XU]) {
 #pragma unroll
-    for (int u = 0; u < CV_XU; ++u)
-        if (tid + CV_THREADS * u < CV_HY * CV_HX * 16) *reinterpret_cast<f32x4*>(xin + st.loff[u]) = v[u];
+    for (int u = 0; u < Geo<DIL>::XU; ++u)
+        if (tid + CV_THREADS * u < Geo<DIL>::HY * Geo<DIL>::HX * 16) *reinterpret_cast<f32x4*>(xin + st.loff[u]) = v[u];
 }
 
 // Persistent workgroups (two per compute unit): workgroup b works through tiles b, b + gridDim, ...
@@ -145,8 +154,10 @@ __device__ __forceinline__ void put_input(float* xin, int tid, const Staging& st
 //     147 KiB for every workgroup (L2-resident), requested CV_BD groups ahead of their use -- an endless periodic stream
 //     (group 72 of a tile is group 0 of the next).  With the weight slices staged through LDS a workgroup needed a barrier
 //     per tap: 0.78 of the matrix peak, the matrix pipe idle a fifth of the time; without, three barriers per tile.
-__global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3x3_c64(ConvArgs a, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float xin[CV_XIN];
+template <int DIL>
+__global__ __launch_bounds__(CV_THREADS, Geo<DIL>::WPS) void k_conv3x3_c64(ConvArgs a, int ntiles) {
+    constexpr int HX = Geo<DIL>::HX;
+    __shared__ __attribute__((aligned(16))) float xin[Geo<DIL>::XIN];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -156,11 +167,11 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    Staging st;
-    staging_init(a, tid, st);
-    f32x4 xpre[CV_XU];
-    fetch_input(a, tile_pos(a, tile), st, xpre);
-    put_input(xin, tid, st, xpre);
+    Staging<DIL> st;
+    staging_init<DIL>(a, tid, st);
+    f32x4 xpre[Geo<DIL>::XU];
+    fetch_input<DIL>(a, tile_pos(a, tile), st, xpre);
+    put_input<DIL>(xin, tid, st, xpre);
     // weight fragments of the first CV_BD groups; ring slot = G % 8 (8 groups per tap: the slot of a group is static)
     f32x4 bq0[CV_RING], bq1[CV_RING];
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3
     // Two workgroups share a compute unit and run the same program: started together they would load, compute and store
     // together, and the matrix cores would idle through every epilogue.  The one that arrived second on its SIMD (wave slot
     // != 0: HW_REG_HW_ID[3:0]) starts a quarter of a tile late, once; after that the two stay out of phase.  Speed only.
-    if (CV_MT == 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {
+    if (Geo<DIL>::WPS > 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) __builtin_amdgcn_s_sleep(127);
     }
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3
         const TilePos q = tile_pos(a, tile);
         const bool more = tile + (int)gridDim.x < ntiles;
         CV_STAMP(0)
-        if (more) fetch_input(a, tile_pos(a, tile + gridDim.x), st, xpre);      // consumed after this tile's nine taps
+        if (more) fetch_input<DIL>(a, tile_pos(a, tile + gridDim.x), st, xpre); // consumed after this tile's nine taps
         CV_STAMP(1)
         f32x16 acc0[CV_MT], acc1[CV_MT];
 #pragma unroll
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int p = (prow + ky) * CV_HX + pcol + kx;       // input pixel of this tap
+            const int p = (prow + ky * DIL) * HX + pcol + kx * DIL;   // input pixel of this tap
             const float* ap = xin + p * CV_PS + kh * 4;          // + 8 g: the tap's eight operand groups are immediate offsets
             // the weight stream is periodic in 72 groups; (tap * 8 + g + CV_BD) % 72 without a division
             int gpre = tap * 8 + CV_BD;
@@ -200,13 +211,13 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3
             // lands under them (left to itself hipcc sinks each read to just before its use)
             f32x4 av[2][CV_MT];
 #pragma unroll
-            for (int mt = 0; mt < CV_MT; ++mt) av[0][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_PS);
+            for (int mt = 0; mt < CV_MT; ++mt) av[0][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * HX * CV_PS);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int cur = g & 1, nxt = cur ^ 1;
                 if (g + 1 < 8) {
 #pragma unroll
-                    for (int mt = 0; mt < CV_MT; ++mt) av[nxt][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * CV_HX * CV_PS + 8 * (g + 1));
+                    for (int mt = 0; mt < CV_MT; ++mt) av[nxt][mt] = *reinterpret_cast<const f32x4*>(ap + 2 * mt * HX * CV_PS + 8 * (g + 1));
                 }
                 {
                     int G = gpre + g;
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(CV_THREADS, (CV_MT == 1 ? CV_WPS : 1)) void k_conv3
         if (more) {
             __syncthreads();                                         // every wave is done with the staging area
             CV_STAMP(5)
-            put_input(xin, tid, st, xpre);
+            put_input<DIL>(xin, tid, st, xpre);
             __syncthreads();
             CV_STAMP(6)
         }
@@ -335,8 +346,17 @@ __global__ __launch_bounds__(256) void k_relayout64(const float* in, float* out,
     }
 }
 
+template <int DIL>
+static hipError_t launch_conv_dil(hipStream_t s, const ConvArgs& a, long long tiles, int cus) {
+    // persistent workgroups (77 KiB of LDS or less: two per compute unit, one otherwise); every workgroup's loop ends: tile < ntiles
+    const long long resident = (long long)Geo<DIL>::WPS * cus;
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    hipLaunchKernelGGL(k_conv3x3_c64<DIL>, dim3(grid), dim3(CV_THREADS), 0, s, a, (int)tiles);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
-                              int n, int H, int W, int relu) {
+                              int n, int H, int W, int relu, int dilation) {
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu;
     a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
@@ -351,11 +371,13 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, con
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    // persistent workgroups, two per compute unit (77 KiB of LDS each); every workgroup's loop ends: tile < ntiles
-    const long long resident = (CV_MT == 1 ? (long long)CV_WPS : 1LL) * cus[dev];
-    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
-    hipLaunchKernelGGL(k_conv3x3_c64, dim3(grid), dim3(CV_THREADS), 0, s, a, (int)tiles);
-    return hipGetLastError();
+    switch (dilation) {
+        case 1: return launch_conv_dil<1>(s, a, tiles, cus[dev]);
+        case 2: return launch_conv_dil<2>(s, a, tiles, cus[dev]);
+        case 3: return launch_conv_dil<3>(s, a, tiles, cus[dev]);
+        case 4: return launch_conv_dil<4>(s, a, tiles, cus[dev]);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw, float* wfrag) {
@@ -381,6 +403,7 @@ hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, 
 //   tail  x [n][H][W][64] (NHWC)  ->  y [n][COUT][H][W] (NCHW, COUT <= 4), + bias: lane cq holds input channels 4 cq .. + 3, the
 //         16 partial sums of a pixel meet by four DPP steps inside the lane row
 // ------------------------------------------------------------------------------------------
+constexpr int CV_HX = Geo<1>::HX, CV_HY = Geo<1>::HY, CV_XU = Geo<1>::XU;      // the direct kernels below: dilation 1
 constexpr int HD_MAXC = 8;
 struct HeadArgs {
     const float* x; const float* w; const float* bias; float* y;

@@ -44,9 +44,11 @@ def _conv_stack(in_nc, out_nc, nc, nb, dilations=None):
 # 64 -> 1..4 channels) stay with PyTorch.  Same weights, same state_dict; the default backend is PyTorch-ROCm / MIOpen.
 # ----------------------------------------------------------------------------------------------
 def _hip_body_ok(conv):
+    """a 64 -> 64 conv3x3, stride 1, dilation d in 1..4 with zero padding d: the layers libpnpmri.so's matrix-core kernel takes
+    (d = 1: DnCNN / FDnCNN / FFDNet bodies, DRUNet's 64-channel blocks; d = 2..4: IRCNN, models/network_dncnn.py:87-101)"""
     return (isinstance(conv, nn.Conv2d) and conv.in_channels == 64 and conv.out_channels == 64 and conv.kernel_size == (3, 3)
-            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and conv.padding_mode == 'zeros')
+            and conv.stride == (1, 1) and conv.dilation[0] == conv.dilation[1] and 1 <= conv.dilation[0] <= 4
+            and conv.padding == conv.dilation and conv.groups == 1 and conv.padding_mode == 'zeros')
 
 
 def _hip_weights(seq, k, conv, L, stream):
@@ -120,7 +122,7 @@ def hip_stack_forward(seq, x):
             n, H, W, _ = nhwc.shape
             out = torch.empty_like(nhwc)
             _lib.check(L.pnp_conv3x3_c64_nhwc(stream, ptr(nhwc), ptr(_hip_weights(seq, k, m, L, stream)), ptr(m.bias), None, ptr(out),
-                                              n, H, W, 1 if relu else 0))
+                                              n, H, W, 1 if relu else 0, m.dilation[0]))
             nhwc = out
             k += 2 if relu else 1
             continue
@@ -176,13 +178,13 @@ class FDnCNN(_PlainStack):
         return self._stack(x)
 
 
-class IRCNN(nn.Module):
+class IRCNN(_PlainStack):
     def __init__(self, in_nc=1, out_nc=1, nc=64):
         super().__init__()
         self.model = _conv_stack(in_nc, out_nc, nc, 7, dilations=[1, 2, 3, 4, 3, 2, 1])
 
     def forward(self, x):
-        return x - self.model(x)
+        return x - self._stack(x)
 
 
 class FFDNet(_PlainStack):
@@ -202,7 +204,7 @@ class FFDNet(_PlainStack):
         return x[..., :h, :w]
 
 
-def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu):
+def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1):
     import ctypes as C
     from . import _lib
     out = torch.empty_like(x_nhwc)
@@ -210,7 +212,7 @@ def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu):
     _lib.check(L.pnp_conv3x3_c64_nhwc(stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()),
                                       None if bias is None else C.c_void_p(bias.data_ptr()),
                                       None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()),
-                                      C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0))
+                                      C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0, int(dilation)))
     return out
 
 
@@ -417,8 +419,8 @@ class Denoiser:
     def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
                  cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch'):
         """backend: 'torch' (default: the whole forward in PyTorch-ROCm / MIOpen, as the north star keeps it) or 'hip' (the
-        64 -> 64 conv3x3 + ReLU body layers of DnCNN / FDnCNN / FFDNet, and DRUNet's 64-channel residual blocks, on
-        libpnpmri.so's fp32-MFMA kernel, float32 only; IRCNN's dilated layers are unaffected)."""
+        64 -> 64 conv3x3 (+ ReLU) layers of DnCNN / FDnCNN / FFDNet / IRCNN (dilations 1..4) and DRUNet's 64-channel residual
+        blocks on libpnpmri.so's fp32-MFMA kernel, the plain stacks' first and last layers on its direct kernels; float32 only)."""
         if backend not in ('torch', 'hip'):
             raise ValueError("backend must be 'torch' or 'hip'")
         if backend == 'hip' and cnn_dtype not in (None, 'fp32'):

@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 from pnp_admm_cnc_mri_amd import _lib  # noqa: E402
 
 n, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (64, 128, 128)
+DIL = int(sys.argv[4]) if len(sys.argv) >= 5 else 1                # dilation (= zero padding) of the layer
 L = _lib.lib()
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
@@ -31,7 +32,7 @@ for w in ws:                                                       # packed once
 
 def hip_conv(xn, w, b, relu, out):
     _lib.check(L.pnp_conv3x3_c64_nhwc(C.c_void_p(stream), C.c_void_p(xn.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
-                                      None, C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0))
+                                      None, C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0, DIL))
     return out
 
 
@@ -47,9 +48,9 @@ _lib.check(L.pnp_relayout_c64(C.c_void_p(stream), C.c_void_p(xn.data_ptr()), C.c
 assert torch.equal(back, x)
 
 torch.backends.cudnn.benchmark = True
-ref1 = F.relu(F.conv2d(x, ws[0], bs[0], padding=1))
+ref1 = F.relu(F.conv2d(x, ws[0], bs[0], padding=DIL, dilation=DIL))
 y1 = hip_conv(xn, wt[0], bs[0], True, torch.empty_like(xn))
-ref64 = F.relu(F.conv2d(x.double(), ws[0].double(), bs[0].double(), padding=1))
+ref64 = F.relu(F.conv2d(x.double(), ws[0].double(), bs[0].double(), padding=DIL, dilation=DIL))
 print('one layer: hip vs torch fp32 %.3e | hip vs fp64 %.3e | torch fp32 vs fp64 %.3e' %
       (rel(y1.permute(0, 3, 1, 2), ref1), rel(y1.permute(0, 3, 1, 2), ref64), rel(ref1, ref64)))
 # chain of 13 conv + ReLU
@@ -58,7 +59,7 @@ r = x
 for k in range(13):
     hip_conv(a, wt[k], bs[k], True, b_)
     a, b_ = b_, (a if a is not xn else torch.empty_like(xn))
-    r = F.relu(F.conv2d(r, ws[k], bs[k], padding=1))
+    r = F.relu(F.conv2d(r, ws[k], bs[k], padding=DIL, dilation=DIL))
 print('13 layers: hip vs torch fp32 %.3e' % rel(a.permute(0, 3, 1, 2), r))
 
 
@@ -78,9 +79,9 @@ def timeit(fn, reps=20):
 flop = 2.0 * n * H * W * 64 * 64 * 9
 o = torch.empty_like(xn)
 t_hip = timeit(lambda: hip_conv(xn, wt[0], bs[0], True, o))
-t_mi = timeit(lambda: F.relu_(F.conv2d(x, ws[0], bs[0], padding=1)))
+t_mi = timeit(lambda: F.relu_(F.conv2d(x, ws[0], bs[0], padding=DIL, dilation=DIL)))
 xcl = x.contiguous(memory_format=torch.channels_last)
 wcl = ws[0].contiguous(memory_format=torch.channels_last)
-t_cl = timeit(lambda: F.relu_(F.conv2d(xcl, wcl, bs[0], padding=1)))
+t_cl = timeit(lambda: F.relu_(F.conv2d(xcl, wcl, bs[0], padding=DIL, dilation=DIL)))
 for name, t in (('hip mfma f32', t_hip), ('miopen nchw', t_mi), ('miopen channels_last', t_cl)):
     print('%-22s %.3f ms  %.1f TFLOP/s  %.3f of 157.3' % (name, t, flop / t / 1e9, flop / t / 1e9 / 157.3))

@@ -14,7 +14,7 @@ w = torch.randn(64, 64, 3, 3, device='cuda') * 0.06; b = torch.zeros(64, device=
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 _lib.check(L.pnp_conv3x3_c64_pack(s, C.c_void_p(w.data_ptr()), C.c_void_p(pk.data_ptr())))
 for _ in range(5):
-    _lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(x.data_ptr()), C.c_void_p(pk.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(y.data_ptr()), n, H, W, 1))
+    _lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(x.data_ptr()), C.c_void_p(pk.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(y.data_ptr()), n, H, W, 1, 1))
 torch.cuda.synchronize()
 out = np.zeros((1024, 8), np.uint64)
 raw = C.CDLL(_lib.LIB_PATH)

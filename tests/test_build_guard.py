@@ -106,12 +106,16 @@ def test_conv_kernel_keeps_two_workgroups_per_compute_unit(asm):
     the other's MFMAs: no scratch, at most 256 VGPRs + AGPRs (2 waves per SIMD), at most 80 KiB of LDS; its MFMAs are the fp32
     32x32x2 form; the generic blend kernel stays at three workgroups per unit (<= 168 VGPRs, 0 scratch)."""
     ks = kernels_of(asm['kernels_conv.hip'])
-    body = [k for n, k in ks.items() if 'k_conv3x3_c64' in n]
-    assert len(body) == 1, sorted(ks)
-    i = body[0]['info']
-    assert i['ScratchSize'] == 0 and i['NumVgprs'] + i['NumAgprs'] <= 256 and i['LDSByteSize'] <= 80 * 1024, i
-    mf = [x for x in body[0]['body'] if x.startswith('v_mfma')]
-    assert len(mf) == 64 and all(x.startswith('v_mfma_f32_32x32x2_f32') for x in mf), len(mf)      # 8 groups x 4 steps x 2 accumulators, taps looped
+    body = {n: k for n, k in ks.items() if 'k_conv3x3_c64' in n}
+    assert len(body) == 4, sorted(ks)                                # dilations 1..4
+    for n, k in body.items():
+        i = k['info']
+        dil = int(n.split('k_conv3x3_c64ILi')[1][0])
+        two = dil <= 2                                                # dilation 1, 2: two workgroups per compute unit; 3, 4: one (82 / 102 KiB of LDS)
+        assert i['ScratchSize'] == 0 and i['LDSByteSize'] <= (80 if two else 160) * 1024, (n, i)
+        assert i['NumVgprs'] + i['NumAgprs'] <= (256 if two else 512), (n, i)
+        mf = [x for x in k['body'] if x.startswith('v_mfma')]
+        assert len(mf) == 64 and all(x.startswith('v_mfma_f32_32x32x2_f32') for x in mf), (n, len(mf))   # 8 groups x 4 steps x 2 accumulators, taps looped
     for n, k in ks.items():
         assert k['info']['ScratchSize'] == 0, (n, k['info'])
     blend = [k for n, k in kernels_of(asm['kernels_generic.hip']).items() if 'k_cols16ILb1ELi1ELb1E' in n]

@@ -182,6 +182,7 @@ def test_hip_backend_needs_gpu_tensors_and_float32():
         D.Denoiser('ffdnet_gray', net, nlm, backend='hip', cnn_dtype='bf16')
     with _pytest.raises(ValueError):
         D.Denoiser('ffdnet_gray', net, nlm, backend='cuda')
-    # the body layers the kernel takes: 13 of FFDNet's 15, 15 of DnCNN-17's, none of IRCNN's dilated ones
+    # the body layers the kernel takes: 13 of FFDNet's 15, 15 of DnCNN-17's, IRCNN's five dilated ones
     count = lambda m: sum(1 for c in m.model if D._hip_body_ok(c))
-    assert count(net) == 13 and count(D.build('dncnn_15')[0]) == 15 and count(D.build('ircnn_gray')[0]) == 0
+    assert count(net) == 13 and count(D.build('dncnn_15')[0]) == 15 and count(D.build('ircnn_gray')[0]) == 5
+    assert all(D.hip_covers_stack(D.build(n)[0].model) for n in ('ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'ircnn_gray'))

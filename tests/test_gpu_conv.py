@@ -26,7 +26,7 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm())
 
 
-def _conv(env, x_nhwc, w_oihw, bias, skip, relu):
+def _conv(env, x_nhwc, w_oihw, bias, skip, relu, dilation=1):
     torch, L, lib = env['torch'], env['L'], env['lib']
     y = torch.empty_like(x_nhwc)
     n, H, W, _ = x_nhwc.shape
@@ -34,7 +34,7 @@ def _conv(env, x_nhwc, w_oihw, bias, skip, relu):
     w9 = torch.empty(9 * 64 * 64, device='cuda')
     lib.check(L.pnp_conv3x3_c64_pack(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(w_oihw.contiguous()), p(w9)))
     lib.check(L.pnp_conv3x3_c64_nhwc(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(x_nhwc), p(w9), p(bias), p(skip), p(y),
-                                     n, H, W, 1 if relu else 0))
+                                     n, H, W, 1 if relu else 0, dilation))
     return y
 
 
@@ -63,6 +63,25 @@ def test_conv3x3_c64_against_pytorch(env, n, H, W, variant):
     x1[0, 7, H // 2, W // 2] = 1.0
     y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False)
     assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.double(), w.double(), padding=1)) <= 1e-6
+
+
+@pytest.mark.parametrize('dilation', [2, 3, 4])
+@pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 5, 23), (1, 1, 1), (5, 128, 128)])
+def test_dilated_conv3x3_c64_against_pytorch(env, n, H, W, dilation):
+    """IRCNN's layers (models/network_dncnn.py:87-101): dilation d = 2, 3, 4 with zero padding d -- a halo of d pixels, taps d apart;
+    images smaller than the halo, not a multiple of the tile, and more tiles than resident workgroups (one per unit at d = 3, 4)"""
+    torch, F = env['torch'], env['F']
+    g = torch.Generator(device='cuda').manual_seed(100 * dilation + n + H)
+    x = torch.randn(n, 64, H, W, device='cuda', generator=g)
+    w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * (2.0 / 576) ** 0.5
+    b = torch.randn(64, device='cuda', generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=dilation, dilation=dilation))
+    y = _conv(env, x.permute(0, 2, 3, 1).contiguous(), w, b, None, True, dilation)
+    assert _rel(y.permute(0, 3, 1, 2), ref) <= 2e-6
+    x1 = torch.zeros(1, 64, H, W, device='cuda')
+    x1[0, 5, H // 2, W // 2] = 1.0                                   # one-hot input, asymmetric weights: every tap must land where PyTorch puts it
+    y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False, dilation)
+    assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.double(), w.double(), padding=dilation, dilation=dilation)) <= 1e-6
 
 
 @pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 16, 16), (2, 5, 23), (1, 1, 1), (4, 128, 128)])
@@ -131,12 +150,15 @@ def test_relayout_round_trip_and_argument_errors(env):
     lib.check(L.pnp_relayout_c64(s, C.c_void_p(xn.data_ptr()), C.c_void_p(back.data_ptr()), 3, 37, 21, 0))
     assert torch.equal(back, x)
     with pytest.raises(lib.PnpError):                        # y must not alias x: a tile reads its neighbours' halo
-        lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(xn.data_ptr()), C.c_void_p(xn.data_ptr()), None, None, C.c_void_p(xn.data_ptr()), 3, 37, 21, 0))
+        lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(xn.data_ptr()), C.c_void_p(xn.data_ptr()), None, None, C.c_void_p(xn.data_ptr()), 3, 37, 21, 0, 1))
     with pytest.raises(lib.PnpError):
-        lib.check(L.pnp_conv3x3_c64_nhwc(s, None, None, None, None, None, 1, 8, 8, 0))
+        lib.check(L.pnp_conv3x3_c64_nhwc(s, None, None, None, None, None, 1, 8, 8, 0, 1))
+    y = torch.empty_like(xn)
+    with pytest.raises(lib.PnpError):                        # dilation outside 1..4
+        lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(xn.data_ptr()), C.c_void_p(xn.data_ptr()), None, None, C.c_void_p(y.data_ptr()), 3, 37, 21, 0, 5))
 
 
-@pytest.mark.parametrize('name', ['ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'dncnn_gray_blind', 'drunet_gray'])
+@pytest.mark.parametrize('name', ['ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'dncnn_gray_blind', 'drunet_gray', 'ircnn_gray'])
 def test_hip_backend_matches_the_pytorch_forward(env, name):
     """Same seeded weights, `Denoiser(backend='hip')` against `backend='torch'` (MIOpen) on 5 slices of 256 x 256 -- and the
     parameters are still the module's own: a load_state_dict after the first call reaches the kernel."""
@@ -148,7 +170,7 @@ def test_hip_backend_matches_the_pytorch_forward(env, name):
     for backend in ('torch', 'hip'):
         net, nlm, _ = D.build(name)
         net.load_state_dict(D.seeded_state_dict(net, 11))
-        sig = torch.tensor([30.0 / 255, 20.0 / 255]) if name.startswith('drunet') else None
+        sig = torch.tensor([30.0 / 255, 20.0 / 255]) if name.startswith(('drunet', 'ircnn')) else None
         den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False).to('cuda')
         outs[backend] = den(x, 0).clone()
         if backend == 'hip':
