@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   8
+#define PNP_ABI_VERSION   9
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -204,6 +204,16 @@ int pnp_conv3x3_c64_nhwc(void* hip_stream, const float* x_dev, const float* w_pa
 /* w_oihw_dev: a torch.nn.Conv2d(64, 64, 3) weight, [64 out][64 in][3][3] contiguous -> w_packed_dev (36 864 floats).  Once
  * per model (again after the weights change). */
 int pnp_conv3x3_c64_pack(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev);
+/* The same layer in SPLIT-HALF arithmetic on the f16 matrix cores ("f16x3"; csrc/kernels_conv_f16x3.hip): every float32 operand
+ * is split into two halves, x = hi + lo / 2048, and a product becomes three v_mfma_f32_32x32x16_f16 (hi*hi, hi*lo, lo*hi: exact
+ * products, float32 accumulation) -- float32-level results (operands carried to 2^-22, tests/test_gpu_conv.py measures the
+ * distance from float64 beside the float32 kernel's) at several times the float32 matrix rate.  Same arguments and semantics as
+ * pnp_conv3x3_c64_nhwc; w_packed from pnp_conv3x3_c64_pack_f16x3 (36 864 floats of storage, a different order: the two packings
+ * are not interchangeable).  Operands must lie within the half range (|x|, |w| <= 65504): beyond it the result is inf / NaN.
+ * New in ABI 9. */
+int pnp_conv3x3_c64_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
+                               const float* skip_dev, float* y_dev, int n, int H, int W, int relu, int dilation);
+int pnp_conv3x3_c64_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev);
 /* First and last layer of the plain stacks (models/network_dncnn.py:52-62, models/network_ffdnet.py:50-56), direct convolutions:
  *   head: x [n][cin][H][W] (NCHW, 1 <= cin <= 8), w a torch Conv2d(cin, 64, 3) weight [64][cin][3][3] -> y [n][H][W][64] (NHWC), + bias, ReLU
  *   tail: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight [cout][64][3][3], 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias

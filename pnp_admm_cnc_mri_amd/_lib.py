@@ -65,6 +65,8 @@ SIGNATURES = {
     'pnp_prepare_loops': (C.c_int, [ctx_p]),
     'pnp_conv3x3_c64_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_c64_pack': (C.c_int, [_vp, _vp, _vp]),
+    'pnp_conv3x3_c64_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv3x3_c64_pack_f16x3': (C.c_int, [_vp, _vp, _vp]),
     'pnp_conv3x3_head_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_tail_nchw': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_relayout_c64': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -75,7 +77,7 @@ SIGNATURES = {
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

@@ -900,6 +900,20 @@ int pnp_conv3x3_c64_pack(void* stream, const float* w_oihw, float* w_packed) {
     HIPCHK(launch_conv_pack_w((hipStream_t)stream, w_oihw, w_packed));
     return PNP_OK;
 }
+int pnp_conv3x3_c64_nhwc_f16x3(void* stream, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                               int n, int H, int W, int relu, int dilation) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: null pointer");
+    if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: n, H, W must be >= 1");
+    if (x == y || skip == y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: y must not alias x or skip (tiles read their neighbours' halo)");
+    if (dilation < 1 || dilation > 4) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: dilation must be 1..4 (got %d)", dilation);
+    HIPCHK(launch_conv3x3_c64_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, H, W, relu, dilation));
+    return PNP_OK;
+}
+int pnp_conv3x3_c64_pack_f16x3(void* stream, const float* w_oihw, float* w_packed) {
+    if (!w_oihw || !w_packed || w_oihw == w_packed) return fail(PNP_E_ARG, "pnp_conv3x3_c64_pack_f16x3: null or aliased pointers");
+    HIPCHK(launch_conv_pack_w_f16x3((hipStream_t)stream, w_oihw, w_packed));
+    return PNP_OK;
+}
 int pnp_conv3x3_head_nhwc(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int cin, int H, int W, int relu) {
     if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_head_nhwc: null pointer");
     if (n < 1 || H < 1 || W < 1 || cin < 1 || cin > 8) return fail(PNP_E_ARG, "pnp_conv3x3_head_nhwc: n, H, W >= 1 and 1 <= cin <= 8 required");

@@ -29,116 +29,10 @@
 //            (buffer loads whose out-of-image pixels fall outside the descriptor's range and return zeros: no branches)
 //   epilogue bias = the accumulators' initial value; the wave's 32 x 64 outputs go through 8 KiB of the idle input tile and
 //            leave as eight 16-byte stores per lane (a 256-byte pixel per 16 lanes); skip and ReLU join there
-#include "internal.h"
-#include <hip/hip_runtime.h>
+#include "conv_common.h"
 
 namespace pnp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#ifndef CV_MT_N
-#define CV_MT_N 1
-#endif
-constexpr int CV_MT = CV_MT_N;                 // M tiles (of 32 pixels = 2 tile rows) per wave: 1 -> 8 x 16 tiles, two workgroups per unit; 2 -> 16 x 16, one
-constexpr int CV_TX = 16, CV_TY = 8 * CV_MT;   // output tile
-constexpr int CV_C = 64;                       // channels in and out
-constexpr int CV_PS = CV_C + 4;                // floats between consecutive pixels of the LDS tile: 272 bytes, so that the 16 lanes a b128
-                                               // read serves per cycle (consecutive pixels, same channels) start 4 banks apart -- and the
-                                               // eight operand groups of a tap are IMMEDIATE offsets of one address (no per-group VALU)
-constexpr int CV_THREADS = 256;
-constexpr int CV_GROUPS = 9 * 8;               // operand groups per tile: 9 taps x 8 groups of 8 input channels
-constexpr int CV_WFRAG = CV_GROUPS * 2 * 64 * 4;          // floats of the packed weights (= 9 * 64 * 64)
-#ifndef CV_BD_N
-#define CV_BD_N 3
-#endif
-#ifndef CV_WPS
-#define CV_WPS 2                               // workgroups per compute unit = waves per SIMD (MT = 1): 2 or 3
-#endif
-#ifndef CV_RING
-#define CV_RING 8                              // register slots of the weight-fragment ring (a power of two > CV_BD_N, dividing 8)
-#endif
-// Tile geometry by dilation DIL (1: the plain stacks and DRUNet; 2..4: IRCNN's dilated layers, models/network_dncnn.py:87-101): the
-// halo is DIL pixels wide, the taps lie DIL pixels apart.  48 / 64 KiB of LDS at DIL 1 / 2 (two workgroups per compute unit), 82 /
-// 102 KiB at DIL 3 / 4 (one).
-template <int DIL> struct Geo {
-    static constexpr int HX = CV_TX + 2 * DIL, HY = CV_TY + 2 * DIL;                    // tile with halo
-    static constexpr int XIN = HY * HX * CV_PS;                                         // floats of the input tile
-    static constexpr int XU = (HY * HX * 16 + CV_THREADS - 1) / CV_THREADS;             // its 16-byte chunks per thread (12 at DIL 1)
-    static constexpr int WPS = (CV_MT == 1 && XIN * 4 <= 80 * 1024) ? CV_WPS : 1;       // workgroups per compute unit
-};
-constexpr int CV_BD = CV_BD_N;                 // weight fragments are requested this many groups ahead of their MFMAs (ring of CV_RING register slots)
-
-#ifdef CV_PROF
-// diagnostic build (profiles/variants.sh build kernels_conv.hip prof "-DCV_PROF"): shader-clock sums per phase, wave 0 of every workgroup
-__device__ unsigned long long g_cvprof[1024 * 8];
-#define CV_STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) psum[k] += t_ - tlast; tlast = t_; }
-#else
-#define CV_STAMP(k)
-#endif
-
-struct ConvArgs {
-    const float* x;       // [n][H][W][64]
-    const float* w;       // packed: [group G = tap * 8 + g][N tile 2][lane 64][4]  (k_conv_pack_w)
-    const float* bias;    // [64] or null
-    const float* skip;    // [n][H][W][64] or null: added AFTER bias (and before the ReLU, if any) -- residual blocks
-    float* y;             // [n][H][W][64]
-    int n, H, W, tiles_x, tiles_y, relu;
-};
-
-// where tile `t` of the launch lies
-struct TilePos { int img, y0, x0; };
-__device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
-    const int per_img = a.tiles_x * a.tiles_y;
-    TilePos q;
-    q.img = t / per_img;
-    const int trem = t - q.img * per_img, ty = trem / a.tiles_x;
-    q.y0 = ty * CV_TY; q.x0 = (trem - ty * a.tiles_x) * CV_TX;
-    return q;
-}
-
-// Per-thread constants of the input staging, computed ONCE: vector instructions issued beside the partner wave's MFMA
-// stream are slow and cost that stream issue slots (phase clocks, profiles/conv_variants_r04.txt), so everything that does not
-// depend on the tile is out of the loop.  Chunk u of thread tid is (tile pixel p = (tid + 256 u) >> 4, channels 4 cq ..).
-template <int DIL> struct Staging {
-    int goff[Geo<DIL>::XU];     // byte offset of the chunk relative to the tile's first halo pixel (row y0 - DIL, column x0 - DIL), or < 0: none
-    int col[Geo<DIL>::XU];      // tile column of the pixel: the only coordinate that needs a test (rows fall out of the buffer range)
-    int loff[Geo<DIL>::XU];     // float offset in the LDS tile
-};
-template <int DIL>
-__device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging<DIL>& st) {
-    constexpr int HX = Geo<DIL>::HX, HY = Geo<DIL>::HY;
-#pragma unroll
-    for (int u = 0; u < Geo<DIL>::XU; ++u) {
-        const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15, r = p / HX, c = p - r * HX;
-        const bool any = idx < HY * HX * 16;
-        st.goff[u] = any ? (r * a.W + c) * (CV_C * 4) + cq * 16 : -1;
-        st.col[u] = c;
-        st.loff[u] = any ? p * CV_PS + cq * 4 : 0;
-    }
-}
-// the input tile of `q` (halo included, zeros outside the image): global -> registers.  Buffer loads with ONE 32-bit offset per
-// access: rows above / below the image fall outside the descriptor's range by themselves (the offset wraps or exceeds it) and
-// the hardware returns zeros; columns left / right of it get such an offset by one select -- no branch around any load.  (As
-// `in ? *ptr : zero` hipcc branched around every one of the twelve loads and waited vmcnt(0) behind each: twelve dependent
-// memory round trips per tile.)
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* base, int H, int W) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((unsigned)H * (unsigned)W * (CV_C * 4u)), 0x00020000);
-}
-template <int DIL>
-__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, const Staging<DIL>& st, f32x4 (&v)[Geo<DIL>::XU]) {
-    const __amdgpu_buffer_rsrc_t rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
-    const int origin = ((q.y0 - DIL) * a.W + (q.x0 - DIL)) * (CV_C * 4);        // may be negative: such offsets are out of range as unsigned
-    const int xlo = DIL - q.x0, xhi = a.W + DIL - q.x0;                          // valid tile columns: xlo <= c < xhi
-#pragma unroll
-    for (int u = 0; u < Geo<DIL>::XU; ++u) {
-        const bool in = st.goff[u] >= 0 && st.col[u] >= xlo && st.col[u] < xhi;
-        const int off = in ? origin + st.goff[u] : -16;
-        const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-        v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
-    }
-}
 template <int DIL>
 __device__ __forceinline__ void put_input(float* xin, int tid, const Staging<DIL>& st, const f32x4 (&v)[Geo<DIL>::XU]) {
 #pragma unroll
@@ -241,58 +135,8 @@ __global__ __launch_bounds__(CV_THREADS, Geo<DIL>::WPS) void k_conv3x3_c64(ConvA
         __syncthreads();                                             // every wave is done with this tile's input
         CV_STAMP(3)
 
-        // ---- epilogue.  Accumulator (reg r, lane) = pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32, channel
-        // lane & 31 (+ 32 for the second tile).  Stored straight from there every lane would issue 32 dword stores per tile,
-        // and such a tail is bound by store ISSUE, not by bandwidth: the wave's 32 x 64 outputs go through its own 8 KiB of the
-        // (now idle) input tile instead and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes.
-        // The skip input joins there; bias before, ReLU after.
-        float* stage = xin + wv * (32 * CV_C);
-        const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
-        const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
-        // pixel it of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
-        // rows below the image are out of the buffer's range (the store is dropped), columns right of it get such an offset
-        const int l4 = lane >> 4;
-        const int obase = ((q.y0 + 2 * CV_MT * wv) * a.W + q.x0 + l4) * (CV_C * 4) + (lane & 15) * 16;
-        const int wlim = a.W - q.x0 - l4;                            // column 4 (it & 3) valid iff < wlim
-#pragma unroll
-        for (int mt = 0; mt < CV_MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                stage[m * CV_C + i] = acc0[mt][r];
-                stage[m * CV_C + i + 32] = acc1[mt][r];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int off[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * (CV_C * 4) : -16;
-            f32x4 sk[8];
-            if (a.skip) {                                            // all eight requests first: one memory round trip, not eight
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const u32x4v k = __builtin_amdgcn_raw_buffer_load_b128(rk, off[it], 0, 0);
-                    sk[it] = f32x4{__uint_as_float(k.x), __uint_as_float(k.y), __uint_as_float(k.z), __uint_as_float(k.w)};
-                }
-            } else {
-#pragma unroll
-                for (int it = 0; it < 8; ++it) sk[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * it + l4) * CV_C + (lane & 15) * 4) + sk[it];
-                if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ry, off[it], 0, 0);
-            }
-            if (mt + 1 < CV_MT) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
+        // ---- epilogue (conv_common.h): the wave's 32 x 64 outputs leave through 8 KiB of the (now idle) input tile
+        store_tile(a, q, xin + wv * (32 * CV_C), wv, lane, acc0, acc1);
         CV_STAMP(4)
         if (more) {
             __syncthreads();                                         // every wave is done with the staging area
@@ -355,6 +199,19 @@ static hipError_t launch_conv_dil(hipStream_t s, const ConvArgs& a, long long ti
     return hipGetLastError();
 }
 
+// compute units of the current device (cached per device): the persistent kernels launch a multiple of it
+int conv_compute_units() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
                               int n, int H, int W, int relu, int dilation) {
     ConvArgs a;
@@ -363,19 +220,13 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, con
     const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     if ((long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;        // one image must fit a signed 32-bit buffer offset (8 M pixels)
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = conv_compute_units();
+    if (ncu <= 0) return hipGetLastError();
     switch (dilation) {
-        case 1: return launch_conv_dil<1>(s, a, tiles, cus[dev]);
-        case 2: return launch_conv_dil<2>(s, a, tiles, cus[dev]);
-        case 3: return launch_conv_dil<3>(s, a, tiles, cus[dev]);
-        case 4: return launch_conv_dil<4>(s, a, tiles, cus[dev]);
+        case 1: return launch_conv_dil<1>(s, a, tiles, ncu);
+        case 2: return launch_conv_dil<2>(s, a, tiles, ncu);
+        case 3: return launch_conv_dil<3>(s, a, tiles, ncu);
+        case 4: return launch_conv_dil<4>(s, a, tiles, ncu);
         default: return hipErrorInvalidValue;
     }
 }
