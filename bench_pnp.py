@@ -42,8 +42,9 @@ def main():
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
     ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'], help='autocast throughput mode, off parity')
-    ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip'],
-                    help="hip = the 64-channel conv3x3 body layers of the plain stacks (FFDNet, DnCNN) on libpnpmri.so's fp32-MFMA kernel")
+    ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip', 'hip_f16x3'],
+                    help="hip = the plain stacks' conv3x3 layers (FFDNet, DnCNN, IRCNN) and DRUNet's 64-channel blocks on libpnpmri.so's "
+                         "fp32-MFMA kernel; hip_f16x3 = the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores")
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True for the whole run')
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)))
     ap.add_argument('--rehearse-gloo', action='store_true', help='N > 1 on a box with ONE GPU: gloo backend, all ranks on cuda:0')
@@ -161,7 +162,7 @@ def main():
             'metric': 'PNP_ADMM_CNC_D iterations/sec on %dx%d slices (%s)' % (H, W, args.model),
             'value': world * K / wall * (B / 512.0), 'unit': 'it/s (512-slice batches)', 'n_gpus': world, 'steps': K,
             'warmup': args.warmup, 'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'dtype': 'f32' if args.cnn_dtype is None else args.cnn_dtype, 'data': 'synthetic (seeded weights)',
+            'dtype': ('f32' if args.cnn_backend != 'hip_f16x3' else 'f32 (conv 64->64: f32 operands as half pairs, exact products, f32 accumulation)') if args.cnn_dtype is None else args.cnn_dtype, 'data': 'synthetic (seeded weights)',
             'config': {'workload': 'PNP_ADMM_CNC_D, %s, %d synthetic %dx%d slices per GPU, %s, S6:569-577 presets'
                                    % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
                        'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend},
@@ -178,7 +179,8 @@ def main():
                          'roofline': {'bound': 'mfma_f32', 'achieved': den_gflops, 'peak': F32_MATRIX_PEAK_GFLOPS, 'unit': 'GFLOP/s',
                                       'frac': den_gflops / F32_MATRIX_PEAK_GFLOPS},
                          'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)' if args.cnn_backend == 'torch' else
-                                 'body layers (64 -> 64 conv3x3 + ReLU) on the fp32-MFMA implicit GEMM of libpnpmri.so (kernels_conv.hip); first / last layer PyTorch-ROCm'},
+                                 'body layers (64 -> 64 conv3x3 + ReLU) on the fp32-MFMA implicit GEMM of libpnpmri.so (kernels_conv.hip); first / last layer on its direct kernels' if args.cnn_backend == 'hip' else
+                                 '64 -> 64 conv3x3 layers in split-half arithmetic on the f16 matrix cores (kernels_conv_f16x3.hip): the fraction is quoted against the FLOAT32 matrix peak and can exceed 1'},
             'x_finite': bool(torch.isfinite(x).all())}) + '\n')
         out.flush()
     eng.close()

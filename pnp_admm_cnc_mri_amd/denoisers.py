@@ -43,6 +43,13 @@ def _conv_stack(in_nc, out_nc, nc, nb, dilations=None):
 # matrix peak at 64 x 64 x 128 x 128 against MIOpen's 0.57) with activations in NHWC; the first and the last layer (1..5 -> 64,
 # 64 -> 1..4 channels) stay with PyTorch.  Same weights, same state_dict; the default backend is PyTorch-ROCm / MIOpen.
 # ----------------------------------------------------------------------------------------------
+HIP_BACKENDS = ('hip', 'hip_f16x3')       # 'hip': float32 matrix cores; 'hip_f16x3': split-half arithmetic on the f16 matrix cores
+
+
+def _hip_math(backend):
+    return 'f16x3' if backend == 'hip_f16x3' else 'f32'
+
+
 def _hip_body_ok(conv):
     """a 64 -> 64 conv3x3, stride 1, dilation d in 1..4 with zero padding d: the layers libpnpmri.so's matrix-core kernel takes
     (d = 1: DnCNN / FDnCNN / FFDNet bodies, DRUNet's 64-channel blocks; d = 2..4: IRCNN, models/network_dncnn.py:87-101)"""
@@ -51,20 +58,25 @@ def _hip_body_ok(conv):
             and conv.padding == conv.dilation and conv.groups == 1 and conv.padding_mode == 'zeros')
 
 
-def _hip_weights(seq, k, conv, L, stream):
-    """conv.weight packed into the HIP kernel's fragment order (pnp_conv3x3_c64_pack), rebuilt when the parameter changes
-    (load_state_dict, bank switches).  Kept outside the state_dict."""
+def _hip_weights(seq, k, conv, L, stream, math='f32'):
+    """conv.weight packed into the HIP kernel's fragment order (pnp_conv3x3_c64_pack, or pnp_conv3x3_c64_pack_f16x3 for the
+    split-half kernel), rebuilt when the parameter changes (load_state_dict, bank switches).  Kept outside the state_dict."""
     import ctypes as C
     from . import _lib
     cache = seq.__dict__.setdefault('_pnp_hip_w', {})
     w = conv.weight
     key = (w.data_ptr(), w._version, str(w.device))
-    hit = cache.get(k)
+    hit = cache.get((k, math))
     if hit is None or hit[0] != key:
         src = w.detach().contiguous()                          # [out][in][3][3] whatever the parameter's memory format
         packed = torch.empty(9 * 64 * 64, dtype=torch.float32, device=w.device)
-        _lib.check(L.pnp_conv3x3_c64_pack(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr())))
-        cache[k] = hit = (key, packed)
+        if math == 'f16x3':
+            if not bool(torch.isfinite(src).all()) or float(src.abs().max()) > 65504.:
+                raise ValueError("backend='hip_f16x3': a convolution weight lies outside the half range (|w| <= 65504)")
+            _lib.check(L.pnp_conv3x3_c64_pack_f16x3(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr())))
+        else:
+            _lib.check(L.pnp_conv3x3_c64_pack(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr())))
+        cache[(k, math)] = hit = (key, packed)
     return hit[1]
 
 
@@ -85,17 +97,19 @@ def _plain3x3(conv):
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros')
 
 
-def hip_stack_forward(seq, x):
+def hip_stack_forward(seq, x, math='f32'):
     """`seq(x)` for a [Conv3x3, ReLU] * (nb - 1) + Conv3x3 stack on libpnpmri.so's convolution kernels: 64 -> 64 layers on the
     fp32-MFMA implicit GEMM, a first layer with <= 8 input channels and a last layer with <= 4 output channels on the direct
     kernels -- DnCNN / FDnCNN / FFDNet then run without a MIOpen call.  Raises if the library or a GPU tensor is missing: no
     silent fallback to another device; layers the kernels do not cover (other channel counts, dilations) run in PyTorch
-    inside the same call."""
+    inside the same call.  math='f16x3': the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores (float32-level
+    results, csrc/kernels_conv_f16x3.hip)."""
     import ctypes as C
     from . import _lib
     if not (x.is_cuda and x.dtype == torch.float32):
         raise RuntimeError("Denoiser(backend='hip') needs float32 CUDA tensors")
     L = _lib.lib()
+    conv64 = L.pnp_conv3x3_c64_nhwc_f16x3 if math == 'f16x3' else L.pnp_conv3x3_c64_nhwc
     stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     mods = list(seq)
@@ -121,8 +135,8 @@ def hip_stack_forward(seq, x):
                     _lib.check(L.pnp_relayout_c64(stream, ptr(h.contiguous()), ptr(nhwc), h.shape[0], h.shape[2], h.shape[3], 1))
             n, H, W, _ = nhwc.shape
             out = torch.empty_like(nhwc)
-            _lib.check(L.pnp_conv3x3_c64_nhwc(stream, ptr(nhwc), ptr(_hip_weights(seq, k, m, L, stream)), ptr(m.bias), None, ptr(out),
-                                              n, H, W, 1 if relu else 0, m.dilation[0]))
+            _lib.check(conv64(stream, ptr(nhwc), ptr(_hip_weights(seq, k, m, L, stream, math)), ptr(m.bias), None, ptr(out),
+                              n, H, W, 1 if relu else 0, m.dilation[0]))
             nhwc = out
             k += 2 if relu else 1
             continue
@@ -157,7 +171,7 @@ class _PlainStack(nn.Module):
     backend = 'torch'
 
     def _stack(self, x):
-        return hip_stack_forward(self.model, x) if self.backend == 'hip' else self.model(x)
+        return hip_stack_forward(self.model, x, _hip_math(self.backend)) if self.backend in HIP_BACKENDS else self.model(x)
 
 
 class DnCNN(_PlainStack):
@@ -204,15 +218,14 @@ class FFDNet(_PlainStack):
         return x[..., :h, :w]
 
 
-def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1):
+def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1, math='f32'):
     import ctypes as C
     from . import _lib
     out = torch.empty_like(x_nhwc)
     n, H, W, _ = x_nhwc.shape
-    _lib.check(L.pnp_conv3x3_c64_nhwc(stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()),
-                                      None if bias is None else C.c_void_p(bias.data_ptr()),
-                                      None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()),
-                                      C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0, int(dilation)))
+    _lib.check((L.pnp_conv3x3_c64_nhwc_f16x3 if math == 'f16x3' else L.pnp_conv3x3_c64_nhwc)(stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()),
+        None if bias is None else C.c_void_p(bias.data_ptr()), None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()),
+        C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0, int(dilation)))
     return out
 
 
@@ -228,7 +241,7 @@ class _ResBlock(nn.Module):
                                  nn.Conv2d(nc, nc, 3, 1, 1, bias=False))
 
     def forward(self, x):
-        if self.backend == 'hip' and _hip_body_ok(self.res[0]) and _hip_body_ok(self.res[2]):
+        if self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0]) and _hip_body_ok(self.res[2]):
             import ctypes as C
             from . import _lib
             if not (x.is_cuda and x.dtype == torch.float32):
@@ -238,8 +251,9 @@ class _ResBlock(nn.Module):
             xn = x.permute(0, 2, 3, 1)
             if not xn.is_contiguous():
                 xn = xn.contiguous()                           # NCHW-contiguous input: one copy; channels_last tensors pass as they are
-            h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream), self.res[0].bias, None, True)
-            y = _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream), self.res[2].bias, xn, False)
+            math = _hip_math(self.backend)
+            h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream, math), self.res[0].bias, None, True, 1, math)
+            y = _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream, math), self.res[2].bias, xn, False, 1, math)
             return y.permute(0, 3, 1, 2)                       # a channels_last NCHW view
         return x + self.res(x)
 
@@ -399,16 +413,16 @@ def forward_flops(den, H, W, device):
             macs[0] += out.numel() * (m.in_channels // m.groups) * kh * kw
 
     hs = [m.register_forward_hook(hook) for m in den.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
-    swapped = [m for m in den.model.modules() if getattr(m, 'backend', None) == 'hip']
-    for m in swapped:
+    swapped = [(m, m.backend) for m in den.model.modules() if getattr(m, 'backend', None) in HIP_BACKENDS]
+    for m, _ in swapped:
         m.backend = 'torch'                  # the probe counts module calls; the HIP backend does the same arithmetic outside them
     try:
         den(torch.rand((1, 1, H, W), dtype=torch.float32, device=device), 0)
     finally:
         for h in hs:
             h.remove()
-        for m in swapped:
-            m.backend = 'hip'
+        for m, b in swapped:
+            m.backend = b
     return 2 * macs[0]
 
 
@@ -420,11 +434,14 @@ class Denoiser:
                  cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch'):
         """backend: 'torch' (default: the whole forward in PyTorch-ROCm / MIOpen, as the north star keeps it) or 'hip' (the
         64 -> 64 conv3x3 (+ ReLU) layers of DnCNN / FDnCNN / FFDNet / IRCNN (dilations 1..4) and DRUNet's 64-channel residual
-        blocks on libpnpmri.so's fp32-MFMA kernel, the plain stacks' first and last layers on its direct kernels; float32 only)."""
-        if backend not in ('torch', 'hip'):
-            raise ValueError("backend must be 'torch' or 'hip'")
-        if backend == 'hip' and cnn_dtype not in (None, 'fp32'):
-            raise ValueError("backend='hip' is float32 only")
+        blocks on libpnpmri.so's fp32-MFMA kernel, the plain stacks' first and last layers on its direct kernels; float32 only)
+        or 'hip_f16x3' (the same, with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores: float32 operands
+        carried as two halves, three exact-product matrix instructions per product, float32 accumulation -- float32-level
+        results at several times the float32 matrix rate; operands must lie within the half range, |x| <= 65504)."""
+        if backend not in ('torch',) + HIP_BACKENDS:
+            raise ValueError("backend must be 'torch', 'hip' or 'hip_f16x3'")
+        if backend in HIP_BACKENDS and cnn_dtype not in (None, 'fp32'):
+            raise ValueError("backend='%s' takes and returns float32 only" % backend)
         self.name, self.fam = model_name, family(model_name)
         self.model = model
         self.backend = backend
@@ -507,7 +524,7 @@ class Denoiser:
         if out is None:
             out = torch.empty_like(x)
         find = (min(B, self.cnn_batch) >= 16 and x.is_cuda) if self.miopen_find == 'auto' else bool(self.miopen_find)
-        if self.backend == 'hip' and isinstance(self.model, _PlainStack) and hip_covers_stack(self.model.model):
+        if self.backend in HIP_BACKENDS and isinstance(self.model, _PlainStack) and hip_covers_stack(self.model.model):
             find = False                      # no MIOpen call in this forward: the process-global flag is left alone
         cd = torch.backends.cudnn
         before = cd.benchmark

@@ -21,7 +21,10 @@ save_E=, device=, return_info=  as in solvers.py, plus
                             False / True: leave the caller's setting alone / force a find for every forward
     cnn_backend='torch'     'torch': the whole CNN forward in PyTorch-ROCm / MIOpen (north star); 'hip': the 64 -> 64 conv3x3 + ReLU
                             body layers of DnCNN / FDnCNN / FFDNet on libpnpmri.so's fp32 matrix-core kernel (exact f32
-                            arithmetic, ~1e-6 from MIOpen's results; first and last layer stay in PyTorch)
+                            arithmetic, ~1e-6 from MIOpen's results; first and last layer on its direct kernels);
+                            'hip_f16x3': the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores
+                            (float32 operands as two halves, exact products, float32 accumulation: float32-level results,
+                            2.3 x the float32 kernel's rate; operands must lie within the half range)
 """
 import os
 

@@ -24,7 +24,8 @@ from conftest import ROOT
 
 CSRC = os.path.join(ROOT, 'pnp_admm_cnc_mri_amd', 'csrc')
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'kernels_conv.hip', 'api.hip']
+SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'kernels_conv.hip', 'kernels_conv_f16x3.hip',
+           'api.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off']     # = csrc/Makefile CXXFLAGS
 
 import importlib.util
@@ -120,6 +121,22 @@ def test_conv_kernel_keeps_two_workgroups_per_compute_unit(asm):
         assert k['info']['ScratchSize'] == 0, (n, k['info'])
     blend = [k for n, k in kernels_of(asm['kernels_generic.hip']).items() if 'k_cols16ILb1ELi1ELb1E' in n]
     assert len(blend) == 1 and blend[0]['info']['NumVgprs'] <= 168 and blend[0]['info']['ScratchSize'] == 0, blend[0]['info']
+
+
+def test_f16x3_conv_kernel_resources(asm):
+    """k_conv3x3_c64_h3: at dilation 1 two workgroups share a compute unit -- 81 728 bytes of LDS each (input tile +
+    two weight buffers: the 160 KiB exactly), at most 256 registers, no scratch; every matrix instruction is the half form with
+    float32 accumulation, 24 per tap (4 K steps x 2 accumulator halves x 3 products)."""
+    ks = {n: k for n, k in kernels_of(asm['kernels_conv_f16x3.hip']).items() if 'k_conv3x3_c64_h3' in n}
+    assert len(ks) == 4, sorted(ks)
+    for n, k in ks.items():
+        i = k['info']
+        dil = int(n.split('k_conv3x3_c64_h3ILi')[1][0])
+        assert i['ScratchSize'] == 0, (n, i)
+        assert i['LDSByteSize'] <= (80 if dil == 1 else 160) * 1024, (n, i)
+        assert i['NumVgprs'] + i['NumAgprs'] <= (256 if dil == 1 else 512), (n, i)
+        mf = [x for x in k['body'] if x.startswith('v_mfma')]
+        assert len(mf) == 24 and all(x.startswith('v_mfma_f32_32x32x16_f16') for x in mf), (n, len(mf), mf[:2])
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():

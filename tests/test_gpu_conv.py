@@ -2,7 +2,12 @@
 64 -> 64 conv3x3 (+ bias, + skip, + ReLU) implicit GEMM on the fp32 matrix cores against a plain PyTorch reference of the
 same op.  fp32 MFMA is an exact f32 fma chain over the 576 products of an output value, so one layer sits at ~5e-7 from the
 float64 result -- the same distance as MIOpen's own fp32 kernels; tolerances: one layer <= 2e-6 (vs float64), whole networks
-<= 1e-5 (vs the PyTorch / MIOpen forward with the same weights)."""
+<= 1e-5 (vs the PyTorch / MIOpen forward with the same weights).
+
+The same layer in split-half arithmetic on the f16 matrix cores (csrc/kernels_conv_f16x3.hip, `backend='hip_f16x3'`: every
+float32 operand as two halves, three exact-product v_mfma_f32_32x32x16_f16 per product, float32 accumulation) is held to the
+SAME tolerances by the same tests (parameter `math`), plus its own: magnitudes from 1e-6 to 1e4, and a loud failure beyond the
+half range."""
 import ctypes as C
 
 import numpy as np
@@ -26,21 +31,24 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm())
 
 
-def _conv(env, x_nhwc, w_oihw, bias, skip, relu, dilation=1):
+def _conv(env, x_nhwc, w_oihw, bias, skip, relu, dilation=1, math='f32'):
     torch, L, lib = env['torch'], env['L'], env['lib']
+    pack, conv = ((L.pnp_conv3x3_c64_pack, L.pnp_conv3x3_c64_nhwc) if math == 'f32' else
+                  (L.pnp_conv3x3_c64_pack_f16x3, L.pnp_conv3x3_c64_nhwc_f16x3))
     y = torch.empty_like(x_nhwc)
     n, H, W, _ = x_nhwc.shape
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     w9 = torch.empty(9 * 64 * 64, device='cuda')
-    lib.check(L.pnp_conv3x3_c64_pack(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(w_oihw.contiguous()), p(w9)))
-    lib.check(L.pnp_conv3x3_c64_nhwc(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(x_nhwc), p(w9), p(bias), p(skip), p(y),
-                                     n, H, W, 1 if relu else 0, dilation))
+    lib.check(pack(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(w_oihw.contiguous()), p(w9)))
+    lib.check(conv(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(x_nhwc), p(w9), p(bias), p(skip), p(y),
+                   n, H, W, 1 if relu else 0, dilation))
     return y
 
 
 @pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 16, 16), (1, 8, 16), (2, 5, 23), (1, 1, 1), (5, 128, 128)])
 @pytest.mark.parametrize('variant', ['bias_relu', 'plain', 'skip_relu'])
-def test_conv3x3_c64_against_pytorch(env, n, H, W, variant):
+@pytest.mark.parametrize('math', ['f32', 'f16x3'])
+def test_conv3x3_c64_against_pytorch(env, n, H, W, variant, math):
     """tiles of 8 x 16 pixels: shapes that are no multiple of the tile, smaller than one tile, a single pixel; more tiles than
     resident workgroups (5 x 128 x 128 = 640 tiles on 512 persistent workgroups: the loop's second trip)"""
     torch, F = env['torch'], env['F']
@@ -56,18 +64,19 @@ def test_conv3x3_c64_against_pytorch(env, n, H, W, variant):
         ref = F.relu(ref)
     xn = x.permute(0, 2, 3, 1).contiguous()
     skn = None if sk is None else sk.permute(0, 2, 3, 1).contiguous()
-    y = _conv(env, xn, w, b, skn, variant != 'plain')
+    y = _conv(env, xn, w, b, skn, variant != 'plain', math=math)
     assert _rel(y.permute(0, 3, 1, 2), ref) <= 2e-6
     # asymmetric weights + an identity-like input catch a transposed tap or channel map: one hot input channel / pixel
     x1 = torch.zeros(1, 64, H, W, device='cuda')
     x1[0, 7, H // 2, W // 2] = 1.0
-    y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False)
+    y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False, math=math)
     assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.double(), w.double(), padding=1)) <= 1e-6
 
 
 @pytest.mark.parametrize('dilation', [2, 3, 4])
 @pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 5, 23), (1, 1, 1), (5, 128, 128)])
-def test_dilated_conv3x3_c64_against_pytorch(env, n, H, W, dilation):
+@pytest.mark.parametrize('math', ['f32', 'f16x3'])
+def test_dilated_conv3x3_c64_against_pytorch(env, n, H, W, dilation, math):
     """IRCNN's layers (models/network_dncnn.py:87-101): dilation d = 2, 3, 4 with zero padding d -- a halo of d pixels, taps d apart;
     images smaller than the halo, not a multiple of the tile, and more tiles than resident workgroups (one per unit at d = 3, 4)"""
     torch, F = env['torch'], env['F']
@@ -76,12 +85,67 @@ def test_dilated_conv3x3_c64_against_pytorch(env, n, H, W, dilation):
     w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * (2.0 / 576) ** 0.5
     b = torch.randn(64, device='cuda', generator=g) * 0.1
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=dilation, dilation=dilation))
-    y = _conv(env, x.permute(0, 2, 3, 1).contiguous(), w, b, None, True, dilation)
+    y = _conv(env, x.permute(0, 2, 3, 1).contiguous(), w, b, None, True, dilation, math)
     assert _rel(y.permute(0, 3, 1, 2), ref) <= 2e-6
     x1 = torch.zeros(1, 64, H, W, device='cuda')
     x1[0, 5, H // 2, W // 2] = 1.0                                   # one-hot input, asymmetric weights: every tap must land where PyTorch puts it
-    y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False, dilation)
+    y1 = _conv(env, x1.permute(0, 2, 3, 1).contiguous(), w, None, None, False, dilation, math)
     assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.double(), w.double(), padding=dilation, dilation=dilation)) <= 1e-6
+
+
+@pytest.mark.parametrize('xs,ws', [('mixed', 1.0), (1e-3, 1e-3), (1.0, 1.0), (300.0, 0.01), (1e4, 1.0), (1.0, 50.0)])
+def test_f16x3_holds_float32_accuracy_over_magnitudes(env, xs, ws):
+    """x = hi + lo / 2048 with both parts halves: relative precision 2^-22 for |x| >= 2^-14 (hi a normal half), an ABSOLUTE
+    precision of 2^-36 = 1.5e-11 below (subnormal halves, which the matrix cores take as they are; the factor 2048 is the largest
+    that keeps `lo` inside the half range for every |x| <= 65504).  Over five decades of operand magnitude -- and with tiny
+    values mixed into ordinary ones -- the distance from the float64 result is no larger than the float32-MFMA kernel's."""
+    torch, F = env['torch'], env['F']
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(2, 64, 48, 40, device='cuda', generator=g)
+    if xs == 'mixed':                                                # one value in eight six decades below the others
+        x = x * torch.where(torch.rand(x.shape, device='cuda', generator=g) < 0.125, 1e-6, 1.0)
+    else:
+        x = x * xs
+    w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * (2.0 / 576) ** 0.5 * ws
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    e16 = _rel(_conv(env, xn, w, None, None, False, math='f16x3').permute(0, 3, 1, 2), ref)
+    e32 = _rel(_conv(env, xn, w, None, None, False, math='f32').permute(0, 3, 1, 2), ref)
+    assert e16 <= 5e-7 and e16 <= 1.25 * e32, (e16, e32)
+
+
+def test_f16x3_precision_floor_of_uniformly_tiny_operands(env):
+    """the documented floor: a tensor whose EVERY value is ~1e-6 (far below 2^-14) is carried to 2^-36 absolute, i.e. ~1e-5 of
+    its own scale -- the one regime where f16x3 is not float32-like.  (A denoiser's activations are O(0.01 .. 1).)"""
+    torch, F = env['torch'], env['F']
+    g = torch.Generator(device='cuda').manual_seed(6)
+    x = torch.randn(2, 64, 48, 40, device='cuda', generator=g) * 1e-6
+    w = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * (2.0 / 576) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    y = _conv(env, x.permute(0, 2, 3, 1).contiguous(), w, None, None, False, math='f16x3').permute(0, 3, 1, 2)
+    assert 1e-6 < _rel(y, ref) <= 3e-5
+    assert float((y.double() - ref).abs().max()) <= 576 ** 0.5 * 6 * 2.0 ** -36 * float(w.abs().max())
+
+
+def test_f16x3_is_loud_outside_the_half_range(env):
+    """an activation beyond +-65504 has no half representation: the outputs it reaches are inf / NaN, never a plausible number;
+    the Python backend refuses such WEIGHTS when it packs them"""
+    torch, D = env['torch'], env['D']
+    x = torch.zeros(1, 64, 16, 16, device='cuda')
+    x[0, 3, 8, 8] = 7e4
+    w = torch.randn(64, 64, 3, 3, device='cuda') * 0.05
+    y = _conv(env, x.permute(0, 2, 3, 1).contiguous(), w, None, None, False, math='f16x3').permute(0, 3, 1, 2)
+    assert not torch.isfinite(y[0, :, 7:10, 7:10]).any()
+    far = torch.ones(16, 16, dtype=torch.bool, device='cuda')
+    far[7:10, 7:10] = False
+    assert torch.isfinite(y[0][:, far]).all()
+    net = D.DnCNN(nb=4)
+    net.load_state_dict(D.seeded_state_dict(net, 1))
+    with torch.no_grad():
+        net.model[2].weight[0, 0, 0, 0] = 1e5
+    net.backend = 'hip_f16x3'
+    with pytest.raises(ValueError):
+        net.cuda()(torch.rand(1, 1, 16, 16, device='cuda'))
 
 
 @pytest.mark.parametrize('n,H,W', [(3, 136, 136), (2, 16, 16), (2, 5, 23), (1, 1, 1), (4, 128, 128)])
@@ -117,16 +181,17 @@ def test_head_and_tail_layers_against_pytorch(env, n, H, W):
         lib.check(L.pnp_conv3x3_tail_nchw(s, p(xn), p(xn), None, p(xn), n, 5, H, W))          # cout > 4
 
 
-def test_hip_backend_of_a_plain_stack_makes_no_miopen_call(env):
+@pytest.mark.parametrize('backend', ['hip', 'hip_f16x3'])
+def test_hip_backend_of_a_plain_stack_makes_no_miopen_call(env, backend):
     """FFDNet with backend='hip': head, 13 body layers and tail all run on libpnpmri.so -- torch.nn.functional.conv2d is never
     reached (checked by making it raise for the duration of the call)."""
     torch, D, F = env['torch'], env['D'], env['F']
     net, nlm, _ = D.build('ffdnet_gray')
     net.load_state_dict(D.seeded_state_dict(net, 3))
-    den = D.Denoiser('ffdnet_gray', net.eval(), nlm, backend='hip', miopen_find=False).to('cuda')
+    den = D.Denoiser('ffdnet_gray', net.eval(), nlm, backend=backend, miopen_find=False).to('cuda')
     x = torch.rand(2, 1, 64, 64, device='cuda')
     ref = D.Denoiser('ffdnet_gray', net, nlm, backend='torch', miopen_find=False)(x, 0).clone()
-    net.backend = 'hip'
+    net.backend = backend
     orig = torch.nn.Conv2d.forward
 
     def boom(self, inp):
@@ -156,10 +221,16 @@ def test_relayout_round_trip_and_argument_errors(env):
     y = torch.empty_like(xn)
     with pytest.raises(lib.PnpError):                        # dilation outside 1..4
         lib.check(L.pnp_conv3x3_c64_nhwc(s, C.c_void_p(xn.data_ptr()), C.c_void_p(xn.data_ptr()), None, None, C.c_void_p(y.data_ptr()), 3, 37, 21, 0, 5))
+    for bad in ((xn, xn, xn, 1), (None, xn, y, 1), (xn, xn, y, 0)):          # the f16x3 entry point checks the same things
+        a_, w_, y_, d_ = bad
+        with pytest.raises(lib.PnpError):
+            lib.check(L.pnp_conv3x3_c64_nhwc_f16x3(s, None if a_ is None else C.c_void_p(a_.data_ptr()), C.c_void_p(w_.data_ptr()), None, None,
+                                                   C.c_void_p(y_.data_ptr()), 3, 37, 21, 0, d_))
 
 
+@pytest.mark.parametrize('hip', ['hip', 'hip_f16x3'])
 @pytest.mark.parametrize('name', ['ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'dncnn_gray_blind', 'drunet_gray', 'ircnn_gray'])
-def test_hip_backend_matches_the_pytorch_forward(env, name):
+def test_hip_backend_matches_the_pytorch_forward(env, name, hip):
     """Same seeded weights, `Denoiser(backend='hip')` against `backend='torch'` (MIOpen) on 5 slices of 256 x 256 -- and the
     parameters are still the module's own: a load_state_dict after the first call reaches the kernel."""
     torch, D = env['torch'], env['D']
@@ -167,24 +238,25 @@ def test_hip_backend_matches_the_pytorch_forward(env, name):
     x = torch.rand(5, 1, 256, 256, device='cuda', generator=g)
     noises = (np.random.default_rng(3).standard_normal((256, 256)) + 1j * np.random.default_rng(4).standard_normal((256, 256))) * 5
     outs = {}
-    for backend in ('torch', 'hip'):
+    for backend in ('torch', hip):
         net, nlm, _ = D.build(name)
         net.load_state_dict(D.seeded_state_dict(net, 11))
         sig = torch.tensor([30.0 / 255, 20.0 / 255]) if name.startswith(('drunet', 'ircnn')) else None
         den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False).to('cuda')
         outs[backend] = den(x, 0).clone()
-        if backend == 'hip':
+        if backend == hip:
             net.load_state_dict(D.seeded_state_dict(net, 12))
             again = den(x, 0).clone()
             net2, _, _ = D.build(name)
             net2.load_state_dict(D.seeded_state_dict(net2, 12))
             ref2 = D.Denoiser(name, net2.eval(), nlm, sigmas=sig, noises=noises, miopen_find=False).to('cuda')(x, 0)
-            assert _rel(again, ref2) <= 1e-5 and _rel(again, outs['hip']) > 1e-3
-    assert _rel(outs['hip'], outs['torch']) <= 1e-5, _rel(outs['hip'], outs['torch'])
-    assert torch.isfinite(outs['hip']).all()
+            assert _rel(again, ref2) <= 1e-5 and _rel(again, outs[hip]) > 1e-3
+    assert _rel(outs[hip], outs['torch']) <= 1e-5, _rel(outs[hip], outs['torch'])
+    assert torch.isfinite(outs[hip]).all()
 
 
-def test_pnp_entry_point_with_the_hip_backend(env, tmp_path):
+@pytest.mark.parametrize('hip', ['hip', 'hip_f16x3'])
+def test_pnp_entry_point_with_the_hip_backend(env, tmp_path, hip):
     """PNP_ADMM_CNC_D(..., cnn_backend='hip') -- FFDNet, S6:573 presets, 6 iterations on 3 synthetic slices -- ends where the
     PyTorch / MIOpen backend ends (the loop contracts: 2e-5 covers the 12 forwards' accumulated difference)."""
     P, D = env['P'], env['D']
@@ -192,12 +264,12 @@ def test_pnp_entry_point_with_the_hip_backend(env, tmp_path):
     mask = S.reference_masks()['Q_Radial30'].astype(np.uint8)
     img, noise = S.batch(300, 3)
     res = {}
-    for backend in ('torch', 'hip'):
+    for backend in ('torch', hip):
         net, _, _ = D.build('ffdnet_gray')
         net.load_state_dict(D.seeded_state_dict(net, 1))
         opts = dict(SP.PRESETS['PNP_ADMM_CNC_D']['ffdnet'], iter_num=6)
         out, _ = SP.PNP_ADMM_CNC_D('ffdnet_gray', mask, noise[0], images=img, model=net, results=str(tmp_path), cnn_backend=backend,
                                    miopen_find=False, **opts)
         res[backend] = np.stack([out[b] for b in range(3)])
-    err = np.linalg.norm(res['hip'] - res['torch']) / np.linalg.norm(res['torch'])
+    err = np.linalg.norm(res[hip] - res['torch']) / np.linalg.norm(res['torch'])
     assert err <= 2e-5, err
