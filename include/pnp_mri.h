@@ -214,6 +214,14 @@ int pnp_conv3x3_c64_pack(void* hip_stream, const float* w_oihw_dev, float* w_pac
 int pnp_conv3x3_c64_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
                                const float* skip_dev, float* y_dev, int n, int H, int W, int relu, int dilation);
 int pnp_conv3x3_c64_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev);
+/* The f16x3 layer for C -> C channels, C a multiple of 64 up to 1024 (DRUNet's residual blocks at 128 / 256 / 512 channels,
+ * models/network_unet.py:36-58 with models/basicblock.py:213-225): dilation 1, zero padding 1; x, y, skip [n][H][W][C] float32
+ * (NHWC); w_packed: 9 C C floats of storage written by pnp_conv3x3_pack_f16x3 from a torch Conv2d(C, C, 3) weight; bias [C] or
+ * NULL.  A workgroup computes 8 x 16 pixels x 64 output channels, its K loop runs over the C / 64 chunks of input channels; one
+ * image must stay below 2 GiB (H W C floats).  C = 64 is the layer above (same packing).  New in ABI 9. */
+int pnp_conv3x3_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
+                           const float* skip_dev, float* y_dev, int n, int C, int H, int W, int relu);
+int pnp_conv3x3_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev, int C);
 /* First and last layer of the plain stacks (models/network_dncnn.py:52-62, models/network_ffdnet.py:50-56), direct convolutions:
  *   head: x [n][cin][H][W] (NCHW, 1 <= cin <= 8), w a torch Conv2d(cin, 64, 3) weight [64][cin][3][3] -> y [n][H][W][64] (NHWC), + bias, ReLU
  *   tail: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight [cout][64][3][3], 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias

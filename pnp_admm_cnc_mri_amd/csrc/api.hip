@@ -906,12 +906,28 @@ int pnp_conv3x3_c64_nhwc_f16x3(void* stream, const float* x, const float* w, con
     if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: n, H, W must be >= 1");
     if (x == y || skip == y) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: y must not alias x or skip (tiles read their neighbours' halo)");
     if (dilation < 1 || dilation > 4) return fail(PNP_E_ARG, "pnp_conv3x3_c64_nhwc_f16x3: dilation must be 1..4 (got %d)", dilation);
-    HIPCHK(launch_conv3x3_c64_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, H, W, relu, dilation));
+    HIPCHK(launch_conv3x3_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, 64, H, W, relu, dilation));
+    return PNP_OK;
+}
+int pnp_conv3x3_nhwc_f16x3(void* stream, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                           int n, int C, int H, int W, int relu) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3: null pointer");
+    if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3: n, H, W must be >= 1");
+    if (C < 64 || C > 1024 || C % 64) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3: C must be a multiple of 64 in 64..1024 (got %d)", C);
+    if ((long long)H * W * C * 4 > 0x7fffffffLL) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3: an image of %d x %d x %d floats exceeds 2 GiB", H, W, C);
+    if (x == y || skip == y) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3: y must not alias x or skip (tiles read their neighbours' halo)");
+    HIPCHK(launch_conv3x3_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, C, H, W, relu, 1));
+    return PNP_OK;
+}
+int pnp_conv3x3_pack_f16x3(void* stream, const float* w_oihw, float* w_packed, int C) {
+    if (!w_oihw || !w_packed || w_oihw == w_packed) return fail(PNP_E_ARG, "pnp_conv3x3_pack_f16x3: null or aliased pointers");
+    if (C < 64 || C > 1024 || C % 64) return fail(PNP_E_ARG, "pnp_conv3x3_pack_f16x3: C must be a multiple of 64 in 64..1024 (got %d)", C);
+    HIPCHK(launch_conv_pack_w_f16x3((hipStream_t)stream, w_oihw, w_packed, C));
     return PNP_OK;
 }
 int pnp_conv3x3_c64_pack_f16x3(void* stream, const float* w_oihw, float* w_packed) {
     if (!w_oihw || !w_packed || w_oihw == w_packed) return fail(PNP_E_ARG, "pnp_conv3x3_c64_pack_f16x3: null or aliased pointers");
-    HIPCHK(launch_conv_pack_w_f16x3((hipStream_t)stream, w_oihw, w_packed));
+    HIPCHK(launch_conv_pack_w_f16x3((hipStream_t)stream, w_oihw, w_packed, 64));
     return PNP_OK;
 }
 int pnp_conv3x3_head_nhwc(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int cin, int H, int W, int relu) {

@@ -56,6 +56,7 @@ struct ConvArgs {
     const float* skip;    // [n][H][W][64] or null: added AFTER bias (and before the ReLU, if any) -- residual blocks
     float* y;             // [n][H][W][64]
     int n, H, W, tiles_x, tiles_y, relu;
+    int C;                // kernels_conv_f16x3.hip: channels in = out, a multiple of 64 (the float32 kernel is 64 only)
 };
 
 // where tile `t` of the launch lies
@@ -78,13 +79,13 @@ template <int DIL> struct Staging {
     int loff[Geo<DIL>::XU];     // float offset in the LDS tile
 };
 template <int DIL>
-__device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging<DIL>& st) {
+__device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging<DIL>& st, const int pix = CV_C * 4) {
     constexpr int HX = Geo<DIL>::HX, HY = Geo<DIL>::HY;
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u) {
         const int idx = tid + CV_THREADS * u, p = idx >> 4, cq = idx & 15, r = p / HX, c = p - r * HX;
         const bool any = idx < HY * HX * 16;
-        st.goff[u] = any ? (r * a.W + c) * (CV_C * 4) + cq * 16 : -1;
+        st.goff[u] = any ? (r * a.W + c) * pix + cq * 16 : -1;
         st.col[u] = c;
         st.loff[u] = any ? p * CV_PS + cq * 4 : 0;
     }
@@ -95,13 +96,15 @@ __device__ __forceinline__ void staging_init(const ConvArgs& a, int tid, Staging
 // `in ? *ptr : zero` hipcc branched around every one of the twelve loads and waited vmcnt(0) behind each: twelve dependent
 // memory round trips per tile.)
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* base, int H, int W) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((unsigned)H * (unsigned)W * (CV_C * 4u)), 0x00020000);
+// `pix`: bytes between consecutive pixels of the tensor (4 x its channel count); `coff`: first channel of the 64 this call touches
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* base, int H, int W, const int pix = CV_C * 4, const int coff = 0) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + coff), 0, (int)((unsigned)H * (unsigned)W * (unsigned)pix - 4u * (unsigned)coff), 0x00020000);
 }
 template <int DIL>
-__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, const Staging<DIL>& st, f32x4 (&v)[Geo<DIL>::XU]) {
-    const __amdgpu_buffer_rsrc_t rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
-    const int origin = ((q.y0 - DIL) * a.W + (q.x0 - DIL)) * (CV_C * 4);        // may be negative: such offsets are out of range as unsigned
+__device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q, const Staging<DIL>& st, f32x4 (&v)[Geo<DIL>::XU],
+                                            const int pix = CV_C * 4, const int coff = 0) {
+    const __amdgpu_buffer_rsrc_t rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
+    const int origin = ((q.y0 - DIL) * a.W + (q.x0 - DIL)) * pix;        // may be negative: such offsets are out of range as unsigned
     const int xlo = DIL - q.x0, xhi = a.W + DIL - q.x0;                          // valid tile columns: xlo <= c < xhi
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u) {
@@ -116,19 +119,20 @@ int conv_compute_units();       // kernels_conv.hip
 
 // The epilogue of a tile: y = relu?(acc + skip) for the wave's 32 x 64 outputs (the bias is already in the accumulators).
 __device__ __forceinline__ void store_tile(const ConvArgs& a, const TilePos& q, float* stage, int wv, int lane,
-                                           const f32x16 (&acc0)[CV_MT], const f32x16 (&acc1)[CV_MT]) {
+                                           const f32x16 (&acc0)[CV_MT], const f32x16 (&acc1)[CV_MT],
+                                           const int pix = CV_C * 4, const int coff = 0) {
     const int i = lane & 31, kh = lane >> 5;
     // Accumulator (reg r, lane) = pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32, channel
     // lane & 31 (+ 32 for the second tile).  Stored straight from there every lane would issue 32 dword stores per tile,
     // and such a tail is bound by store ISSUE, not by bandwidth: the wave's 32 x 64 outputs go through its own 8 KiB of the
     // (now idle) input tile instead and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes.
     // The skip input joins there; bias before, ReLU after.
-    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
-    const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * CV_C, a.H, a.W);
+    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
+    const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
     // pixel it of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
     // rows below the image are out of the buffer's range (the store is dropped), columns right of it get such an offset
     const int l4 = lane >> 4;
-    const int obase = ((q.y0 + 2 * CV_MT * wv) * a.W + q.x0 + l4) * (CV_C * 4) + (lane & 15) * 16;
+    const int obase = ((q.y0 + 2 * CV_MT * wv) * a.W + q.x0 + l4) * pix + (lane & 15) * 16;
     const int wlim = a.W - q.x0 - l4;                            // column 4 (it & 3) valid iff < wlim
 #pragma unroll
     for (int mt = 0; mt < CV_MT; ++mt) {
@@ -144,7 +148,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const TilePos& q, 
         int off[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it)
-            off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * (CV_C * 4) : -16;
+            off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * pix : -16;
         f32x4 sk[8];
         if (a.skip) {                                            // all eight requests first: one memory round trip, not eight
 #pragma unroll

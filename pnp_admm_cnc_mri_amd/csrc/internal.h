@@ -78,9 +78,9 @@ hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw /*[64][64][3][3
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
                               float* y, int n, int H, int W, int relu, int dilation /* 1..4 */);
 // the same layer in split-half arithmetic on the f16 matrix cores (kernels_conv_f16x3.hip): own packing, same buffer size
-hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw, float* wfrag);
-hipError_t launch_conv3x3_c64_f16x3(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
-                                    float* y, int n, int H, int W, int relu, int dilation /* 1..4 */);
+hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw /*[C][C][3][3]*/, float* wfrag /*9 C C floats*/, int C);
+hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
+                                float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */);
 hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc);
 hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                                int n, int cin, int H, int W, int relu);

@@ -60,7 +60,7 @@ __device__ __forceinline__ void put_input_h3(float* xin, int tid, const Staging<
 }
 
 template <int DIL>
-__global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(ConvArgs a, int ntiles) {
+__global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(ConvArgs a, int nitems) {
     constexpr int HX = Geo<DIL>::HX;
     __shared__ __attribute__((aligned(16))) float xin[Geo<DIL>::XIN];
     __shared__ __attribute__((aligned(16))) f32x4 wbuf[2][H3_TAP16];
@@ -68,15 +68,21 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const int prow = 2 * wv + (i >> 4), pcol = i & 15;          // this lane's pixel of the wave's 32 (tile coordinates)
-    const float bias0 = a.bias ? a.bias[i] : 0.f, bias1 = a.bias ? a.bias[i + 32] : 0.f;
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.w) + tid;       // + tap * 1024 + 256 j: this thread's four units of a tap
+    // C = 64 NC channels: an ITEM is (tile, block cb of 64 output channels), its K loop runs over NC chunks of 64 input channels
+    // x 9 taps.  item = tile * NC + cb and gridDim.x is a multiple of NC (launch): a workgroup keeps its cb, so its weight
+    // stream -- [cb][chunk][tap] blocks of 16 KiB -- is periodic in 9 NC taps, and on an 8-XCD part every XCD works on NC / 8 ..
+    // 1 blocks of output channels whose weights (147 KiB x NC) stay in ITS L2 while the input tiles stream.
+    const int NC = a.C >> 6, pix = a.C * 4, period = 9 * NC;
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    const int cb = item % NC;
+    const float bias0 = a.bias ? a.bias[64 * cb + i] : 0.f, bias1 = a.bias ? a.bias[64 * cb + i + 32] : 0.f;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.w) + (size_t)cb * period * H3_TAP16 + tid;   // + t * 1024 + 256 j: tap t of the stream
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
     Staging<DIL> st;
-    staging_init<DIL>(a, tid, st);
+    staging_init<DIL>(a, tid, st, pix);
     f32x4 xpre[Geo<DIL>::XU];
-    fetch_input<DIL>(a, tile_pos(a, tile), st, xpre);
+    fetch_input<DIL>(a, tile_pos(a, item / NC), st, xpre, pix, 0);
     f32x4 wreg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wreg[j] = wsrc[256 * j];
@@ -85,122 +91,134 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     for (int j = 0; j < 4; ++j) wbuf[0][tid + 256 * j] = wreg[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wreg[j] = wsrc[H3_TAP16 + 256 * j];
-    int par = 0;                                                 // buffer of the current tap; 9 taps per tile: it alternates across tiles
+    int par = 0;                                                 // buffer of the current tap
+    int t2 = 2 >= period ? 2 - period : 2;                       // stream position of the weights requested next (two taps ahead)
     // the workgroup that arrived second on its SIMDs starts late, once (kernels_conv.hip): the two stay out of phase
-    if (GeoH<DIL>::WPS > 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {
-#pragma unroll 1
-        for (int k = 0; k < 1; ++k) __builtin_amdgcn_s_sleep(127);
-    }
+    if (GeoH<DIL>::WPS > 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_sleep(127);
 
 #pragma unroll 1
-    for (; tile < ntiles; tile += gridDim.x) {
-        const TilePos q = tile_pos(a, tile);
-        const bool more = tile + (int)gridDim.x < ntiles;
-        if (more) fetch_input<DIL>(a, tile_pos(a, tile + gridDim.x), st, xpre);  // consumed after this tile's nine taps
+    for (; item < nitems; item += gridDim.x) {
+        const TilePos q = tile_pos(a, item / NC);
         f32x16 main0, main1, corr0, corr1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { main0[r] = bias0; main1[r] = bias1; corr0[r] = 0.f; corr1[r] = 0.f; }
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            // wbuf[par] (and, at tap 0, the input tile) is complete; every wave is done with wbuf[par ^ 1]
-            __syncthreads();
+        for (int cc = 0; cc < NC; ++cc) {
+            // the input tile that follows this one -- the tile's next 64 input channels, or the first 64 of the next item -- is
+            // requested now and consumed after this chunk's nine taps
+            const bool last = cc + 1 == NC;
+            const bool more = !last || item + (int)gridDim.x < nitems;
+            if (more) fetch_input<DIL>(a, last ? tile_pos(a, (item + gridDim.x) / NC) : q, st, xpre, pix, last ? 0 : 64 * (cc + 1));
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                // wbuf[par] (and, at tap 0, the input tile) is complete; every wave is done with wbuf[par ^ 1]
+                __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wbuf[par ^ 1][tid + 256 * j] = wreg[j];            // the next tap's weights
-            {
-                const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;                      // the stream is periodic in 9 taps
+                for (int j = 0; j < 4; ++j) wbuf[par ^ 1][tid + 256 * j] = wreg[j];        // the next tap's weights
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wreg[j] = wsrc[t2 * H3_TAP16 + 256 * j];
-            }
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int p = (prow + ky * DIL) * HX + pcol + kx * DIL;                       // input pixel of this tap
-            const char* ap = reinterpret_cast<const char*>(xin) + p * (CV_PS * 4) + kh * 16;   // + 32 s: K step s; + 128: the lo halves
-            const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;        // + 1024 f: fragment f = (2 s + nt) * 2 + part
-            h8 ah[2], al[2], bh[2][2], bl[2][2];
+                t2 = t2 + 1 == period ? 0 : t2 + 1;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int p = (prow + ky * DIL) * HX + pcol + kx * DIL;                   // input pixel of this tap
+                const char* ap = reinterpret_cast<const char*>(xin) + p * (CV_PS * 4) + kh * 16;   // + 32 s: K step s; + 128: the lo halves
+                const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;        // + 1024 f: fragment f = (2 s + nt) * 2 + part
+                h8 ah[2], al[2], bh[2][2], bl[2][2];
 #define H3_LOAD(slot, s_)                                                                  \
-            ah[slot] = *reinterpret_cast<const h8*>(ap + 32 * (s_));                       \
-            al[slot] = *reinterpret_cast<const h8*>(ap + 32 * (s_) + 128);                 \
-            bh[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 0));        \
-            bl[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 1));        \
-            bh[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 2));        \
-            bl[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 3));
-            H3_LOAD(0, 0)
+                ah[slot] = *reinterpret_cast<const h8*>(ap + 32 * (s_));                   \
+                al[slot] = *reinterpret_cast<const h8*>(ap + 32 * (s_) + 128);             \
+                bh[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 0));    \
+                bl[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 1));    \
+                bh[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 2));    \
+                bl[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 3));
+                H3_LOAD(0, 0)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s + 1 < 4) { H3_LOAD(nxt, s + 1) }
-                __builtin_amdgcn_sched_barrier(0);
-                main0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur][0], main0, 0, 0, 0);
-                main1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur][1], main1, 0, 0, 0);
-                corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur][0], corr0, 0, 0, 0);
-                corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur][1], corr1, 0, 0, 0);
-                corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur][0], corr0, 0, 0, 0);
-                corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur][1], corr1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int s = 0; s < 4; ++s) {
+                    const int cur = s & 1, nxt = cur ^ 1;
+                    if (s + 1 < 4) { H3_LOAD(nxt, s + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    main0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur][0], main0, 0, 0, 0);
+                    main1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur][1], main1, 0, 0, 0);
+                    corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur][0], corr0, 0, 0, 0);
+                    corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur][1], corr1, 0, 0, 0);
+                    corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur][0], corr0, 0, 0, 0);
+                    corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur][1], corr1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #undef H3_LOAD
-            par ^= 1;
-        }
-        __syncthreads();                                             // every wave is done with this tile's input
-        f32x16 acc0[1], acc1[1];
+                par ^= 1;
+            }
+            __syncthreads();                                         // every wave is done with this chunk's input
+            if (last) {
+                f32x16 acc0[1], acc1[1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc0[0][r] = fmaf(corr0[r], H3_RSCALE, main0[r]);
-            acc1[0][r] = fmaf(corr1[r], H3_RSCALE, main1[r]);
-        }
-        store_tile(a, q, xin + wv * (32 * CV_C), wv, lane, acc0, acc1);
-        if (more) {
-            __syncthreads();                                         // every wave is done with the staging area
-            put_input_h3<DIL>(xin, tid, st, xpre);                   // published by the barrier of the next tile's first tap
+                for (int r = 0; r < 16; ++r) {
+                    acc0[0][r] = fmaf(corr0[r], H3_RSCALE, main0[r]);
+                    acc1[0][r] = fmaf(corr1[r], H3_RSCALE, main1[r]);
+                }
+                store_tile(a, q, xin + wv * (32 * CV_C), wv, lane, acc0, acc1, pix, 64 * cb);
+                if (more) __syncthreads();                           // every wave is done with the staging area
+            }
+            if (more) put_input_h3<DIL>(xin, tid, st, xpre);         // published by the barrier of the next chunk's first tap
         }
     }
 }
 
-// torch.nn.Conv2d weight [64 out][64 in][3][3] -> split halves in fragment order: half j of lane (n, kb) of fragment
-// (tap, K step s, N tile nt, part) is part(W[out = 32 nt + n][in = 16 s + 8 kb + j][tap]) -- v_mfma_f32_32x32x16_f16: lane l
-// supplies B[k = 8 (l >> 5) + j][column l & 31]; the A side reads input channels in the same order.  The same 147 456 bytes
-// as the float32 packing.  Once per model.
-__global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Float16* wfrag) {
-    const int o = blockIdx.x * 256 + threadIdx.x;                 // one (hi, lo) pair per thread
-    if (o >= 9 * 64 * 64) return;
-    const int j = o & 7, lane = (o >> 3) & 63, nt = (o >> 9) & 1, s = (o >> 10) & 3, tap = o >> 12;
-    const int out = 32 * nt + (lane & 31), in = 16 * s + 8 * (lane >> 5) + j;
-    const float w = w_oihw[((size_t)out * 64 + in) * 9 + tap];
+// torch.nn.Conv2d weight [C out][C in][3][3] -> split halves in fragment order, blocks [cb][chunk cc][tap] of 16 KiB: half j of lane
+// (n, kb) of fragment (K step s, N tile nt, part) is part(W[out = 64 cb + 32 nt + n][in = 64 cc + 16 s + 8 kb + j][tap]) --
+// v_mfma_f32_32x32x16_f16: lane l supplies B[k = 8 (l >> 5) + j][column l & 31]; the A side reads input channels in the same
+// order.  As many bytes as the float32 weights.  Once per model.
+__global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Float16* wfrag, int C) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;      // one (hi, lo) pair per thread
+    if (o >= 9LL * C * C) return;
+    const int NC = C >> 6;
+    const int j = o & 7, lane = (o >> 3) & 63, nt = (o >> 9) & 1, s = (o >> 10) & 3;
+    const long long blk = o >> 12;                                // (cb * NC + cc) * 9 + tap
+    const int tap = (int)(blk % 9), cc = (int)((blk / 9) % NC), cb = (int)(blk / (9 * NC));
+    const int out = 64 * cb + 32 * nt + (lane & 31), in = 64 * cc + 16 * s + 8 * (lane >> 5) + j;
+    const float w = w_oihw[((size_t)out * C + in) * 9 + tap];
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)((w - (float)hi) * H3_SCALE);
-    const size_t frag = ((size_t)(tap * 4 + s) * 2 + nt) * 2;    // the hi fragment; lo follows
+    const size_t frag = ((size_t)blk * 4 + s) * 4 + nt * 2;      // the hi fragment; lo follows
     wfrag[(frag * 64 + lane) * 8 + j] = hi;
     wfrag[((frag + 1) * 64 + lane) * 8 + j] = lo;
 }
 
 template <int DIL>
-static hipError_t launch_h3_dil(hipStream_t s, const ConvArgs& a, long long tiles, int cus) {
-    const long long resident = (long long)GeoH<DIL>::WPS * cus;  // persistent workgroups; every workgroup's loop ends: tile < ntiles
-    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
-    hipLaunchKernelGGL(k_conv3x3_c64_h3<DIL>, dim3(grid), dim3(CV_THREADS), 0, s, a, (int)tiles);
+static hipError_t launch_h3_dil(hipStream_t s, const ConvArgs& a, long long items, int cus) {
+    // persistent workgroups, a multiple of NC = C / 64 of them (a workgroup keeps its block of output channels); every
+    // workgroup's loop ends: item < nitems
+    const int NC = a.C >> 6;
+    long long grid = (long long)GeoH<DIL>::WPS * cus;
+    grid -= grid % NC;
+    if (grid < NC) grid = NC;
+    if (items < grid) grid = items;                               // items = tiles * NC: a multiple of NC as well
+    hipLaunchKernelGGL(k_conv3x3_c64_h3<DIL>, dim3((unsigned)grid), dim3(CV_THREADS), 0, s, a, (int)items);
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_c64_f16x3(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
-                                    int n, int H, int W, int relu, int dilation) {
+hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                                int n, int C, int H, int W, int relu, int dilation) {
+    if (C < 64 || C > 1024 || (C & 63) || (C != 64 && dilation != 1)) return hipErrorInvalidValue;
     ConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu;
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu; a.C = C;
     a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
-    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
-    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    if ((long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;        // one image must fit a signed 32-bit buffer offset
+    const long long items = (long long)n * a.tiles_x * a.tiles_y * (C >> 6);
+    if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((long long)H * W * C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;           // one image must fit a signed 32-bit buffer offset
     const int cus = conv_compute_units();
     if (cus <= 0) return hipGetLastError();
     switch (dilation) {
-        case 1: return launch_h3_dil<1>(s, a, tiles, cus);
-        case 2: return launch_h3_dil<2>(s, a, tiles, cus);
-        case 3: return launch_h3_dil<3>(s, a, tiles, cus);
-        case 4: return launch_h3_dil<4>(s, a, tiles, cus);
+        case 1: return launch_h3_dil<1>(s, a, items, cus);
+        case 2: return launch_h3_dil<2>(s, a, items, cus);
+        case 3: return launch_h3_dil<3>(s, a, items, cus);
+        case 4: return launch_h3_dil<4>(s, a, items, cus);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw, float* wfrag) {
-    hipLaunchKernelGGL(k_conv_pack_w_h3, dim3(9 * 64 * 64 / 256), dim3(256), 0, s, w_oihw, reinterpret_cast<_Float16*>(wfrag));
+hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw, float* wfrag, int C) {
+    if (C < 64 || C > 1024 || (C & 63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv_pack_w_h3, dim3((unsigned)(9LL * C * C / 256)), dim3(256), 0, s, w_oihw, reinterpret_cast<_Float16*>(wfrag), C);
     return hipGetLastError();
 }
 

@@ -50,12 +50,17 @@ def _hip_math(backend):
     return 'f16x3' if backend == 'hip_f16x3' else 'f32'
 
 
-def _hip_body_ok(conv):
-    """a 64 -> 64 conv3x3, stride 1, dilation d in 1..4 with zero padding d: the layers libpnpmri.so's matrix-core kernel takes
-    (d = 1: DnCNN / FDnCNN / FFDNet bodies, DRUNet's 64-channel blocks; d = 2..4: IRCNN, models/network_dncnn.py:87-101)"""
-    return (isinstance(conv, nn.Conv2d) and conv.in_channels == 64 and conv.out_channels == 64 and conv.kernel_size == (3, 3)
-            and conv.stride == (1, 1) and conv.dilation[0] == conv.dilation[1] and 1 <= conv.dilation[0] <= 4
-            and conv.padding == conv.dilation and conv.groups == 1 and conv.padding_mode == 'zeros')
+def _hip_body_ok(conv, math='f32'):
+    """a 64 -> 64 conv3x3, stride 1, dilation d in 1..4 with zero padding d: the layers libpnpmri.so's matrix-core kernels take
+    (d = 1: DnCNN / FDnCNN / FFDNet bodies, DRUNet's 64-channel blocks; d = 2..4: IRCNN, models/network_dncnn.py:87-101); the
+    f16x3 kernel also takes C -> C channels for C = 128 .. 1024 in steps of 64 at d = 1 (DRUNet's other scales)"""
+    if not (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1
+            and conv.padding_mode == 'zeros' and conv.dilation[0] == conv.dilation[1] and conv.padding == conv.dilation
+            and conv.in_channels == conv.out_channels):
+        return False
+    if conv.in_channels == 64:
+        return 1 <= conv.dilation[0] <= 4
+    return math == 'f16x3' and conv.in_channels % 64 == 0 and 64 < conv.in_channels <= 1024 and conv.dilation[0] == 1
 
 
 def _hip_weights(seq, k, conv, L, stream, math='f32'):
@@ -69,11 +74,11 @@ def _hip_weights(seq, k, conv, L, stream, math='f32'):
     hit = cache.get((k, math))
     if hit is None or hit[0] != key:
         src = w.detach().contiguous()                          # [out][in][3][3] whatever the parameter's memory format
-        packed = torch.empty(9 * 64 * 64, dtype=torch.float32, device=w.device)
+        packed = torch.empty(9 * conv.in_channels * conv.out_channels, dtype=torch.float32, device=w.device)
         if math == 'f16x3':
             if not bool(torch.isfinite(src).all()) or float(src.abs().max()) > 65504.:
                 raise ValueError("backend='hip_f16x3': a convolution weight lies outside the half range (|w| <= 65504)")
-            _lib.check(L.pnp_conv3x3_c64_pack_f16x3(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr())))
+            _lib.check(L.pnp_conv3x3_pack_f16x3(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr()), conv.in_channels))
         else:
             _lib.check(L.pnp_conv3x3_c64_pack(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr())))
         cache[(k, math)] = hit = (key, packed)
@@ -222,7 +227,12 @@ def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1, ma
     import ctypes as C
     from . import _lib
     out = torch.empty_like(x_nhwc)
-    n, H, W, _ = x_nhwc.shape
+    n, H, W, ch = x_nhwc.shape
+    if ch != 64:                                                   # DRUNet's 128- / 256- / 512-channel blocks: f16x3 only (_hip_body_ok)
+        _lib.check(L.pnp_conv3x3_nhwc_f16x3(
+            stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()), None if bias is None else C.c_void_p(bias.data_ptr()),
+            None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()), C.c_void_p(out.data_ptr()), n, ch, H, W, 1 if relu else 0))
+        return out
     _lib.check((L.pnp_conv3x3_c64_nhwc_f16x3 if math == 'f16x3' else L.pnp_conv3x3_c64_nhwc)(stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()),
         None if bias is None else C.c_void_p(bias.data_ptr()), None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()),
         C.c_void_p(out.data_ptr()), n, H, W, 1 if relu else 0, int(dilation)))
@@ -241,7 +251,8 @@ class _ResBlock(nn.Module):
                                  nn.Conv2d(nc, nc, 3, 1, 1, bias=False))
 
     def forward(self, x):
-        if self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0]) and _hip_body_ok(self.res[2]):
+        if (self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0], _hip_math(self.backend))
+                and _hip_body_ok(self.res[2], _hip_math(self.backend))):
             import ctypes as C
             from . import _lib
             if not (x.is_cuda and x.dtype == torch.float32):

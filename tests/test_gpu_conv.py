@@ -114,6 +114,39 @@ def test_f16x3_holds_float32_accuracy_over_magnitudes(env, xs, ws):
     assert e16 <= 5e-7 and e16 <= 1.25 * e32, (e16, e32)
 
 
+@pytest.mark.parametrize('ch,n,H,W', [(128, 3, 40, 56), (256, 2, 24, 24), (512, 2, 32, 32), (192, 1, 5, 23), (128, 40, 64, 64), (1024, 1, 9, 9)])
+@pytest.mark.parametrize('variant', ['bias_relu', 'skip'])
+def test_f16x3_wide_layers_against_pytorch(env, ch, n, H, W, variant):
+    """C -> C channels, C a multiple of 64 (DRUNet's residual blocks at 128 / 256 / 512 channels, models/network_unet.py:36-58):
+    items (tile, 64 output channels) x chunks of 64 input channels.  Shapes off the tile grid, more items than resident
+    workgroups (40 x 32 tiles x 2 blocks), a channel count that is no power of two, the largest count accepted."""
+    torch, F, L, lib = env['torch'], env['F'], env['L'], env['lib']
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    g = torch.Generator(device='cuda').manual_seed(ch + 10 * n + H)
+    x = torch.randn(n, H, W, ch, device='cuda', generator=g)
+    w = torch.randn(ch, ch, 3, 3, device='cuda', generator=g) * (2.0 / (9 * ch)) ** 0.5
+    b = torch.randn(ch, device='cuda', generator=g) * 0.1 if variant == 'bias_relu' else None
+    sk = torch.randn(n, H, W, ch, device='cuda', generator=g) if variant == 'skip' else None
+    pk = torch.empty(9 * ch * ch, device='cuda')
+    lib.check(L.pnp_conv3x3_pack_f16x3(s, p(w), p(pk), ch))
+    y = torch.empty_like(x)
+    lib.check(L.pnp_conv3x3_nhwc_f16x3(s, p(x), p(pk), p(b), p(sk), p(y), n, ch, H, W, 1 if variant == 'bias_relu' else 0))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None if b is None else b.double(), padding=1)
+    ref = F.relu(ref) if variant == 'bias_relu' else ref + sk.permute(0, 3, 1, 2).double()
+    assert _rel(y.permute(0, 3, 1, 2), ref) <= 2e-6
+    x1 = torch.zeros(1, H, W, ch, device='cuda')
+    x1[0, H // 2, W // 2, ch - 3] = 1.0                             # one hot value in the LAST chunk of input channels
+    y1 = torch.empty_like(x1)
+    lib.check(L.pnp_conv3x3_nhwc_f16x3(s, p(x1), p(pk), None, None, p(y1), 1, ch, H, W, 0))
+    assert _rel(y1.permute(0, 3, 1, 2), F.conv2d(x1.permute(0, 3, 1, 2).double(), w.double(), padding=1)) <= 1e-6
+    for bad_c in (0, 32, 96, 1088):
+        with pytest.raises(lib.PnpError):
+            lib.check(L.pnp_conv3x3_nhwc_f16x3(s, p(x), p(pk), None, None, p(y), n, bad_c, H, W, 0))
+        with pytest.raises(lib.PnpError):
+            lib.check(L.pnp_conv3x3_pack_f16x3(s, p(w), p(pk), bad_c))
+
+
 def test_f16x3_precision_floor_of_uniformly_tiny_operands(env):
     """the documented floor: a tensor whose EVERY value is ~1e-6 (far below 2^-14) is carried to 2^-36 absolute, i.e. ~1e-5 of
     its own scale -- the one regime where f16x3 is not float32-like.  (A denoiser's activations are O(0.01 .. 1).)"""
