@@ -35,6 +35,14 @@ template <int DIL> struct GeoH {
 };
 static_assert(CV_MT == 1, "the f16x3 kernel is written for one M tile per wave");
 
+#ifdef H3_PROF
+// diagnostic build (profiles/variants.sh build kernels_conv_f16x3.hip h3prof "-DH3_PROF"): shader-clock sums per phase, wave 0 of every workgroup
+__device__ unsigned long long g_h3prof[1024 * 8];
+#define H3_STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) psum[k] += t_ - tlast; tlast = t_; }
+#else
+#define H3_STAMP(k)
+#endif
+
 __device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -44,18 +52,64 @@ __device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
     }
 }
 
-// registers -> LDS tile, split on the way: chunk u of thread tid = 4 consecutive channels of tile pixel p
+// Input staging with ONE register per 16-byte chunk (the float32 kernel's Staging<> keeps three; this kernel is at the 256-register
+// line of two workgroups per compute unit): chunk u of thread tid is tile pixel p = (tid >> 4) + 16 u = (row r, column c), channels
+// 4 (tid & 15) ..; pk[u] = (r W + c) * pix | c -- pix is a multiple of 256, the low byte is free for the column, the only
+// coordinate that needs a test (rows fall out of the buffer range by themselves) -- or -1: no such chunk.
+template <int DIL> struct StagingP { int pk[Geo<DIL>::XU]; };
 template <int DIL>
-__device__ __forceinline__ void put_input_h3(float* xin, int tid, const Staging<DIL>& st, const f32x4 (&v)[Geo<DIL>::XU]) {
-    const int cq = tid & 15;
+__device__ __forceinline__ void staging_init_p(const ConvArgs& a, int tid, StagingP<DIL>& st, const int pix) {
+    constexpr int HX = Geo<DIL>::HX, HY = Geo<DIL>::HY;
+#pragma unroll
+    for (int u = 0; u < Geo<DIL>::XU; ++u) {
+        const int p = (tid >> 4) + 16 * u, r = p / HX, c = p - r * HX;
+        st.pk[u] = (tid + CV_THREADS * u < HY * HX * 16) ? (((r * a.W + c) * pix) | c) : -1;
+    }
+}
+// The request for an input tile is cut into pieces that are issued one per tap: vector-memory results return in order, so a wait for
+// the weights of the next tap also waits for every older request -- a whole tile requested at once in front of a tap would be
+// waited for one tap later.  FetchP holds what the pieces share.
+struct FetchP { __amdgpu_buffer_rsrc_t rs; int origin, xlo, xhi; };
+template <int DIL>
+__device__ __forceinline__ FetchP fetch_begin(const ConvArgs& a, const TilePos& q, int tid, const int pix, const int coff, const bool any = true) {
+    FetchP f;
+    // any = false: a descriptor of zero bytes -- every piece is still ISSUED (hipcc counts the loads in flight exactly only when
+    // they are unconditional: behind an `if` it waits for all of them at the next wait) but none reaches memory
+    f.rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * (pix >> 2), any ? a.H : 0, a.W, pix, any ? coff : 0);
+    f.origin = ((q.y0 - DIL) * a.W + (q.x0 - DIL)) * pix + 16 * (tid & 15);    // may be negative: such offsets are out of range as unsigned
+    f.xlo = DIL - q.x0; f.xhi = a.W + DIL - q.x0;                              // valid tile columns: xlo <= c < xhi
+    return f;
+}
+template <int DIL, int U0, int U1>
+__device__ __forceinline__ void fetch_piece(const FetchP& f, const StagingP<DIL>& st, f32x4 (&v)[Geo<DIL>::XU]) {
+#pragma unroll
+    for (int u = U0; u < U1 && u < Geo<DIL>::XU; ++u) {
+        const int c = st.pk[u] & 255;
+        const bool in = st.pk[u] >= 0 && c >= f.xlo && c < f.xhi;
+        const int off = in ? f.origin + (st.pk[u] & ~255) : -16;
+        const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(f.rs, off, 0, 0);
+        v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+    }
+}
+template <int DIL>
+__device__ __forceinline__ void fetch_input_p(const ConvArgs& a, const TilePos& q, const StagingP<DIL>& st, f32x4 (&v)[Geo<DIL>::XU],
+                                              int tid, const int pix, const int coff) {
+    const FetchP f = fetch_begin<DIL>(a, q, tid, pix, coff);
+    fetch_piece<DIL, 0, Geo<DIL>::XU>(f, st, v);
+}
+
+// registers -> LDS tile, split on the way: chunk u of thread tid = 4 consecutive channels cq of tile pixel (tid >> 4) + 16 u --
+// one base address per thread, the chunks are immediate offsets
+template <int DIL>
+__device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&v)[Geo<DIL>::XU]) {
+    char* px = reinterpret_cast<char*>(xin) + (tid >> 4) * (CV_PS * 4) + 8 * (tid & 15);
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u)
         if (tid + CV_THREADS * u < Geo<DIL>::HY * Geo<DIL>::HX * 16) {
             h4 hi, lo;
             split4(v[u], hi, lo);
-            char* px = reinterpret_cast<char*>(xin + st.loff[u] - 4 * cq);       // the pixel's 272 bytes
-            *reinterpret_cast<h4*>(px + 8 * cq) = hi;
-            *reinterpret_cast<h4*>(px + 128 + 8 * cq) = lo;
+            *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4)) = hi;
+            *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4) + 128) = lo;
         }
 }
 
@@ -79,14 +133,14 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     const float bias0 = a.bias ? a.bias[64 * cb + i] : 0.f, bias1 = a.bias ? a.bias[64 * cb + i + 32] : 0.f;
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.w) + (size_t)cb * period * H3_TAP16 + tid;   // + t * 1024 + 256 j: tap t of the stream
 
-    Staging<DIL> st;
-    staging_init<DIL>(a, tid, st, pix);
+    StagingP<DIL> st;
+    staging_init_p<DIL>(a, tid, st, pix);
     f32x4 xpre[Geo<DIL>::XU];
-    fetch_input<DIL>(a, tile_pos(a, item / NC), st, xpre, pix, 0);
+    fetch_input_p<DIL>(a, tile_pos(a, item / NC), st, xpre, tid, pix, 0);
     f32x4 wreg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wreg[j] = wsrc[256 * j];
-    put_input_h3<DIL>(xin, tid, st, xpre);
+    put_input_h3<DIL>(xin, tid, xpre);
 #pragma unroll
     for (int j = 0; j < 4; ++j) wbuf[0][tid + 256 * j] = wreg[j];
 #pragma unroll
@@ -96,28 +150,42 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     // the workgroup that arrived second on its SIMDs starts late, once (kernels_conv.hip): the two stay out of phase
     if (GeoH<DIL>::WPS > 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_sleep(127);
 
+#ifdef H3_PROF
+    unsigned long long psum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
     for (; item < nitems; item += gridDim.x) {
         const TilePos q = tile_pos(a, item / NC);
         f32x16 main0, main1, corr0, corr1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { main0[r] = bias0; main1[r] = bias1; corr0[r] = 0.f; corr1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { main0[r] = 0.f; main1[r] = 0.f; corr0[r] = 0.f; corr1[r] = 0.f; }
 #pragma unroll 1
         for (int cc = 0; cc < NC; ++cc) {
             // the input tile that follows this one -- the tile's next 64 input channels, or the first 64 of the next item -- is
             // requested now and consumed after this chunk's nine taps
             const bool last = cc + 1 == NC;
             const bool more = !last || item + (int)gridDim.x < nitems;
-            if (more) fetch_input<DIL>(a, last ? tile_pos(a, (item + gridDim.x) / NC) : q, st, xpre, pix, last ? 0 : 64 * (cc + 1));
-#pragma unroll 1
+            H3_STAMP(0)
+            const FetchP nx = fetch_begin<DIL>(a, last && more ? tile_pos(a, (item + gridDim.x) / NC) : q, tid, pix, last ? 0 : 64 * (cc + 1), more);
+            H3_STAMP(1)
+            constexpr int PIECE = (Geo<DIL>::XU + 5) / 6;           // the next input tile: requested in six pieces, behind the weights of taps 0..5
+#pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 // wbuf[par] (and, at tap 0, the input tile) is complete; every wave is done with wbuf[par ^ 1]
                 __syncthreads();
+                H3_STAMP(2)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wbuf[par ^ 1][tid + 256 * j] = wreg[j];        // the next tap's weights
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wreg[j] = wsrc[t2 * H3_TAP16 + 256 * j];
                 t2 = t2 + 1 == period ? 0 : t2 + 1;
+                if (tap == 0) fetch_piece<DIL, 0 * PIECE, 1 * PIECE>(nx, st, xpre);
+                if (tap == 1) fetch_piece<DIL, 1 * PIECE, 2 * PIECE>(nx, st, xpre);
+                if (tap == 2) fetch_piece<DIL, 2 * PIECE, 3 * PIECE>(nx, st, xpre);
+                if (tap == 3) fetch_piece<DIL, 3 * PIECE, 4 * PIECE>(nx, st, xpre);
+                if (tap == 4) fetch_piece<DIL, 4 * PIECE, 5 * PIECE>(nx, st, xpre);
+                if (tap == 5) fetch_piece<DIL, 5 * PIECE, 6 * PIECE>(nx, st, xpre);
+                H3_STAMP(3)
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const int p = (prow + ky * DIL) * HX + pcol + kx * DIL;                   // input pixel of this tap
                 const char* ap = reinterpret_cast<const char*>(xin) + p * (CV_PS * 4) + kh * 16;   // + 32 s: K step s; + 128: the lo halves
@@ -146,22 +214,35 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 }
 #undef H3_LOAD
                 par ^= 1;
+                H3_STAMP(4)
             }
             __syncthreads();                                         // every wave is done with this chunk's input
+            H3_STAMP(5)
             if (last) {
                 f32x16 acc0[1], acc1[1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    acc0[0][r] = fmaf(corr0[r], H3_RSCALE, main0[r]);
-                    acc1[0][r] = fmaf(corr1[r], H3_RSCALE, main1[r]);
+                    acc0[0][r] = fmaf(corr0[r], H3_RSCALE, main0[r]) + bias0;     // (as initial values of the accumulators the two
+                    acc1[0][r] = fmaf(corr1[r], H3_RSCALE, main1[r]) + bias1;     // biases cost hipcc 32 registers kept across the loop)
                 }
                 store_tile(a, q, xin + wv * (32 * CV_C), wv, lane, acc0, acc1, pix, 64 * cb);
+                H3_STAMP(6)
                 if (more) __syncthreads();                           // every wave is done with the staging area
             }
-            if (more) put_input_h3<DIL>(xin, tid, st, xpre);         // published by the barrier of the next chunk's first tap
+            if (more) put_input_h3<DIL>(xin, tid, xpre);         // published by the barrier of the next chunk's first tap
+            H3_STAMP(7)
         }
     }
+#ifdef H3_PROF
+    if (tid == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) g_h3prof[blockIdx.x * 8 + k] = psum[k];
+#endif
 }
+
+#ifdef H3_PROF
+extern "C" int pnp_conv_h3_prof_read(unsigned long long* out /* [1024][8] */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h3prof), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 // torch.nn.Conv2d weight [C out][C in][3][3] -> split halves in fragment order, blocks [cb][chunk cc][tap] of 16 KiB: half j of lane
 // (n, kb) of fragment (K step s, N tile nt, part) is part(W[out = 64 cb + 32 nt + n][in = 64 cc + 16 s + 8 kb + j][tap]) --

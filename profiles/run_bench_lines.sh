@@ -32,3 +32,8 @@ python3 bench_pnp.py --model drunet_gray --size 512 --batch 64 --cnn-batch 16 --
 python3 bench_pnp.py --model dncnn_15 --batch 512 --steps 3 --warmup 1 --cnn-backend $be > $O/pnp_dncnn15_$be.json 2>/dev/null; tail -1 $O/pnp_dncnn15_$be.json | cut -c1-300
 done
 python3 bench_pnp.py --model ffdnet_gray --batch 64 --steps 3 --warmup 1 --gpus 2 --rehearse-gloo > $O/pnp_ffdnet_gpus2_rehearsal.json 2>/dev/null; tail -1 $O/pnp_ffdnet_gpus2_rehearsal.json | cut -c1-200
+# the split-half (f16x3) convolution backend: every model family
+for m in "ffdnet_gray 512 6 2" "dncnn_15 512 3 1" "ircnn_gray 512 3 1" "drunet_gray 512 2 1"; do set -- $m
+python3 bench_pnp.py --model $1 --batch $2 --steps $3 --warmup $4 --cnn-backend hip_f16x3 > $O/pnp_$1_f16x3.json 2>/dev/null; tail -1 $O/pnp_$1_f16x3.json | cut -c1-300
+done
+python3 bench_pnp.py --model drunet_gray --size 512 --batch 64 --cnn-batch 16 --steps 2 --warmup 1 --cnn-backend hip_f16x3 > $O/pnp_drunet512_f16x3.json 2>/dev/null; tail -1 $O/pnp_drunet512_f16x3.json | cut -c1-300
