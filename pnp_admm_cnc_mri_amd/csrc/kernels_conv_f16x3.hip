@@ -166,19 +166,60 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             const bool last = cc + 1 == NC;
             const bool more = !last || item + (int)gridDim.x < nitems;
             H3_STAMP(0)
+#ifndef H3_ABL_NOXPRE
             const FetchP nx = fetch_begin<DIL>(a, last && more ? tile_pos(a, (item + gridDim.x) / NC) : q, tid, pix, last ? 0 : 64 * (cc + 1), more);
+#else
+            const FetchP nx = fetch_begin<DIL>(a, q, tid, pix, 0, false);
+#endif
             H3_STAMP(1)
             constexpr int PIECE = (Geo<DIL>::XU + 5) / 6;           // the next input tile: requested in six pieces, behind the weights of taps 0..5
+            // One tap = 4 K steps of 6 MFMAs.  What a wave's critical path sees of a tap besides its MFMAs is kept short: the A
+            // operands of step 0 are read BEFORE the barrier (the input tile does not change inside a chunk), only the B reads of
+            // step 0 stand between the barrier and the first MFMA, and the next tap's weights go to LDS (and the request for the
+            // tap after that leaves) behind step 0's MFMAs.
+            h8 ah[2], al[2], bh[2][2], bl[2][2];
+#define H3_LOAD_A(slot, ap_, s_)                                                           \
+            ah[slot] = *reinterpret_cast<const h8*>((ap_) + 32 * (s_));                    \
+            al[slot] = *reinterpret_cast<const h8*>((ap_) + 32 * (s_) + 128);
+#define H3_LOAD_B(slot, s_)                                                                \
+            bh[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 0));        \
+            bl[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 1));        \
+            bh[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 2));        \
+            bl[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 3));
+#define H3_MFMA(slot)                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            main0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bh[slot][0], main0, 0, 0, 0);         \
+            main1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bh[slot][1], main1, 0, 0, 0);         \
+            corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bl[slot][0], corr0, 0, 0, 0);         \
+            corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bl[slot][1], corr1, 0, 0, 0);         \
+            corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[slot], bh[slot][0], corr0, 0, 0, 0);         \
+            corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[slot], bh[slot][1], corr1, 0, 0, 0);         \
+            __builtin_amdgcn_sched_barrier(0);
+            const char* const a0 = reinterpret_cast<const char*>(xin) + (prow * HX + pcol) * (CV_PS * 4) + kh * 16;   // tap (0, 0); + 32 s: K step s; + 128: the lo halves
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const char* ap = a0 + (ky * DIL * HX + kx * DIL) * (CV_PS * 4);                     // input pixel of this tap
+                const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;          // + 1024 f: fragment f = (2 s + nt) * 2 + part
                 // wbuf[par] (and, at tap 0, the input tile) is complete; every wave is done with wbuf[par ^ 1]
+#ifndef H3_ABL_NOBAR                                                  // H3_ABL_*: timing-only ablations (results wrong by design), profiles/experiments/abl_conv_f16x3.sh
                 __syncthreads();
+#endif
                 H3_STAMP(2)
+                if (tap == 0) { H3_LOAD_A(0, ap, 0) }                 // taps 1..8: read at the end of the tap before
+                H3_LOAD_B(0, 0)
+                H3_LOAD_A(1, ap, 1)
+                H3_LOAD_B(1, 1)
+                H3_MFMA(0)
+#ifndef H3_ABL_NOWWRITE
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wbuf[par ^ 1][tid + 256 * j] = wreg[j];        // the next tap's weights
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wreg[j] = wsrc[t2 * H3_TAP16 + 256 * j];
+#ifndef H3_ABL_WSAME
                 t2 = t2 + 1 == period ? 0 : t2 + 1;
+#endif
                 if (tap == 0) fetch_piece<DIL, 0 * PIECE, 1 * PIECE>(nx, st, xpre);
                 if (tap == 1) fetch_piece<DIL, 1 * PIECE, 2 * PIECE>(nx, st, xpre);
                 if (tap == 2) fetch_piece<DIL, 2 * PIECE, 3 * PIECE>(nx, st, xpre);
@@ -186,36 +227,23 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 if (tap == 4) fetch_piece<DIL, 4 * PIECE, 5 * PIECE>(nx, st, xpre);
                 if (tap == 5) fetch_piece<DIL, 5 * PIECE, 6 * PIECE>(nx, st, xpre);
                 H3_STAMP(3)
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                const int p = (prow + ky * DIL) * HX + pcol + kx * DIL;                   // input pixel of this tap
-                const char* ap = reinterpret_cast<const char*>(xin) + p * (CV_PS * 4) + kh * 16;   // + 32 s: K step s; + 128: the lo halves
-                const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;        // + 1024 f: fragment f = (2 s + nt) * 2 + part
-                h8 ah[2], al[2], bh[2][2], bl[2][2];
-#define H3_LOAD(slot, s_)                                                                  \
-                ah[slot] = *reinterpret_cast<const h8*>(ap + 32 * (s_));                   \
-                al[slot] = *reinterpret_cast<const h8*>(ap + 32 * (s_) + 128);             \
-                bh[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 0));    \
-                bl[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 1));    \
-                bh[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 2));    \
-                bl[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 3));
-                H3_LOAD(0, 0)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int cur = s & 1, nxt = cur ^ 1;
-                    if (s + 1 < 4) { H3_LOAD(nxt, s + 1) }
-                    __builtin_amdgcn_sched_barrier(0);
-                    main0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur][0], main0, 0, 0, 0);
-                    main1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur][1], main1, 0, 0, 0);
-                    corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur][0], corr0, 0, 0, 0);
-                    corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur][1], corr1, 0, 0, 0);
-                    corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur][0], corr0, 0, 0, 0);
-                    corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur][1], corr1, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                H3_LOAD_A(0, ap, 2)
+                H3_LOAD_B(0, 2)
+                H3_MFMA(1)
+                H3_LOAD_A(1, ap, 3)
+                H3_LOAD_B(1, 3)
+                H3_MFMA(0)
+                if (tap + 1 < 9) {
+                    const int ky1 = (tap + 1) / 3, kx1 = tap + 1 - 3 * ky1;
+                    H3_LOAD_A(0, a0 + (ky1 * DIL * HX + kx1 * DIL) * (CV_PS * 4), 0)
                 }
-#undef H3_LOAD
+                H3_MFMA(1)
                 par ^= 1;
                 H3_STAMP(4)
             }
+#undef H3_LOAD_A
+#undef H3_LOAD_B
+#undef H3_MFMA
             __syncthreads();                                         // every wave is done with this chunk's input
             H3_STAMP(5)
             if (last) {
@@ -225,11 +253,19 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                     acc0[0][r] = fmaf(corr0[r], H3_RSCALE, main0[r]) + bias0;     // (as initial values of the accumulators the two
                     acc1[0][r] = fmaf(corr1[r], H3_RSCALE, main1[r]) + bias1;     // biases cost hipcc 32 registers kept across the loop)
                 }
+#ifndef H3_ABL_NOEPI
                 store_tile(a, q, xin + wv * (32 * CV_C), wv, lane, acc0, acc1, pix, 64 * cb);
+#else
+                if (acc0[0][0] + acc1[0][3] == 123.456f) a.y[tid] = 1.f;
+#endif
                 H3_STAMP(6)
                 if (more) __syncthreads();                           // every wave is done with the staging area
             }
+#ifndef H3_ABL_NOPUT
             if (more) put_input_h3<DIL>(xin, tid, xpre);         // published by the barrier of the next chunk's first tap
+#else
+            if (more && xpre[0][0] + xpre[5][1] + xpre[11][2] == 123.456f) a.y[tid] = 2.f;
+#endif
             H3_STAMP(7)
         }
     }
