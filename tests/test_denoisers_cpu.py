@@ -186,3 +186,27 @@ def test_hip_backend_needs_gpu_tensors_and_float32():
     count = lambda m: sum(1 for c in m.model if D._hip_body_ok(c))
     assert count(net) == 13 and count(D.build('dncnn_15')[0]) == 15 and count(D.build('ircnn_gray')[0]) == 5
     assert all(D.hip_covers_stack(D.build(n)[0].model) for n in ('ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'ircnn_gray'))
+
+
+def test_f16x3_backend_selection_on_the_cpu():
+    """`backend='hip_f16x3'`: same rules as 'hip' (no CPU computation, float32 only); which layers it takes -- the 64-channel
+    ones of every family as 'hip' does, and DRUNet's 128 / 256 / 512-channel residual blocks on top (dilation 1 only)"""
+    import pytest as _pytest
+    import torch.nn as nn
+    from pnp_admm_cnc_mri_amd import denoisers as D
+    net, nlm, _ = D.build('dncnn_15')
+    den = D.Denoiser('dncnn_15', net.eval(), nlm, backend='hip_f16x3', miopen_find=False)
+    assert net.backend == 'hip_f16x3' and D._hip_math(net.backend) == 'f16x3' and D._hip_math('hip') == 'f32'
+    with _pytest.raises(RuntimeError, match='CUDA'):
+        den(torch.rand(1, 1, 32, 32), 0)
+    with _pytest.raises(ValueError):
+        D.Denoiser('dncnn_15', net, nlm, backend='hip_f16x3', cnn_dtype='fp16')
+    unet, nlm2, _ = D.build('drunet_gray')
+    D.Denoiser('drunet_gray', unet.eval(), nlm2, sigmas=torch.tensor([0.1]), backend='hip_f16x3')
+    blocks = [m for m in unet.modules() if isinstance(m, D._ResBlock)]
+    assert len(blocks) == 28 and all(m.backend == 'hip_f16x3' for m in blocks)
+    taken = lambda math: sum(1 for m in blocks if D._hip_body_ok(m.res[0], math) and D._hip_body_ok(m.res[2], math))
+    assert taken('f32') == 8 and taken('f16x3') == 28            # float32 kernel: the 64-channel scale only
+    assert not D._hip_body_ok(nn.Conv2d(128, 128, 3, 1, 2, dilation=2), 'f16x3')      # wide layers: dilation 1 only
+    assert not D._hip_body_ok(nn.Conv2d(96, 96, 3, 1, 1), 'f16x3') and not D._hip_body_ok(nn.Conv2d(128, 64, 3, 1, 1), 'f16x3')
+    assert D._hip_body_ok(nn.Conv2d(1024, 1024, 3, 1, 1), 'f16x3') and not D._hip_body_ok(nn.Conv2d(1088, 1088, 3, 1, 1), 'f16x3')
