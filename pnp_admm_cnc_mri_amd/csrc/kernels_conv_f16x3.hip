@@ -116,8 +116,11 @@ __device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&
 template <int DIL>
 __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(ConvArgs a, int nitems) {
     constexpr int HX = Geo<DIL>::HX;
-    __shared__ __attribute__((aligned(16))) float xin[Geo<DIL>::XIN];
-    __shared__ __attribute__((aligned(16))) f32x4 wbuf[2][H3_TAP16];
+    // ONE LDS array (input tile, then the two weight buffers): with LDS-DMA in flight hipcc orders accesses to separate arrays
+    // conservatively
+    __shared__ __attribute__((aligned(16))) float lds[Geo<DIL>::XIN + 2 * H3_TAP16 * 4];
+    float* const xin = lds;
+    f32x4 (*const wbuf)[H3_TAP16] = reinterpret_cast<f32x4 (*)[H3_TAP16]>(lds + Geo<DIL>::XIN);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -137,16 +140,18 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     staging_init_p<DIL>(a, tid, st, pix);
     f32x4 xpre[Geo<DIL>::XU];
     fetch_input_p<DIL>(a, tile_pos(a, item / NC), st, xpre, tid, pix, 0);
-    f32x4 wreg[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wreg[j] = wsrc[256 * j];
+    // A tap's weights travel global memory -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write): wave w copies
+    // units w * 64 + lane + 256 j of the 1024, one tap ahead of their use.  Completion is this wave's vmcnt; visibility to the
+    // other waves the barrier after the wait.
+#define H3_DMA(buf_, t_)                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                           \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (t_) * H3_TAP16 + 256 * j), \
+                                         (__attribute__((address_space(3))) void*)(&wbuf[buf_][wv * 64 + 256 * j]), 16, 0, 0);
+    H3_DMA(0, 0)
     put_input_h3<DIL>(xin, tid, xpre);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wbuf[0][tid + 256 * j] = wreg[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wreg[j] = wsrc[H3_TAP16 + 256 * j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int par = 0;                                                 // buffer of the current tap
-    int t2 = 2 >= period ? 2 - period : 2;                       // stream position of the weights requested next (two taps ahead)
+    int t1 = 1 >= period ? 0 : 1;                                // stream position of the next tap's weights
     // the workgroup that arrived second on its SIMDs starts late, once (kernels_conv.hip): the two stay out of phase
     if (GeoH<DIL>::WPS > 1 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_sleep(127);
 
@@ -202,9 +207,22 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 const char* ap = a0 + (ky * DIL * HX + kx * DIL) * (CV_PS * 4);                     // input pixel of this tap
                 const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;          // + 1024 f: fragment f = (2 s + nt) * 2 + part
                 // wbuf[par] (and, at tap 0, the input tile) is complete; every wave is done with wbuf[par ^ 1]
+                // this wave's DMA of this tap's weights has landed (the pieces of the input prefetch issued behind it may still be
+                // in flight: a counted wait), its LDS reads are back; then the barrier -- raw: __syncthreads() would drain vmcnt
+#define H3_WAIT_BUT(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory");
+#define H3_PIECE_LOADS(k_) ((k_) * PIECE >= Geo<DIL>::XU ? 0 : ((k_) + 1) * PIECE <= Geo<DIL>::XU ? PIECE : Geo<DIL>::XU - (k_) * PIECE)
+                if (tap == 0 || tap >= 7) { H3_WAIT_BUT(0) }          // nothing was requested behind the tap before's DMA
+                if (tap == 1) { H3_WAIT_BUT(H3_PIECE_LOADS(0)) }
+                if (tap == 2) { H3_WAIT_BUT(H3_PIECE_LOADS(1)) }
+                if (tap == 3) { H3_WAIT_BUT(H3_PIECE_LOADS(2)) }
+                if (tap == 4) { H3_WAIT_BUT(H3_PIECE_LOADS(3)) }
+                if (tap == 5) { H3_WAIT_BUT(H3_PIECE_LOADS(4)) }
+                if (tap == 6) { H3_WAIT_BUT(H3_PIECE_LOADS(5)) }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef H3_ABL_NOBAR                                                  // H3_ABL_*: timing-only ablations (results wrong by design), profiles/experiments/abl_conv_f16x3.sh
-                __syncthreads();
+                __builtin_amdgcn_s_barrier();
 #endif
+                asm volatile("" ::: "memory");
                 H3_STAMP(2)
                 if (tap == 0) { H3_LOAD_A(0, ap, 0) }                 // taps 1..8: read at the end of the tap before
                 H3_LOAD_B(0, 0)
@@ -212,13 +230,10 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 H3_LOAD_B(1, 1)
                 H3_MFMA(0)
 #ifndef H3_ABL_NOWWRITE
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wbuf[par ^ 1][tid + 256 * j] = wreg[j];        // the next tap's weights
+                H3_DMA(par ^ 1, t1)                                  // the next tap's weights
 #endif
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wreg[j] = wsrc[t2 * H3_TAP16 + 256 * j];
 #ifndef H3_ABL_WSAME
-                t2 = t2 + 1 == period ? 0 : t2 + 1;
+                t1 = t1 + 1 == period ? 0 : t1 + 1;
 #endif
                 if (tap == 0) fetch_piece<DIL, 0 * PIECE, 1 * PIECE>(nx, st, xpre);
                 if (tap == 1) fetch_piece<DIL, 1 * PIECE, 2 * PIECE>(nx, st, xpre);
