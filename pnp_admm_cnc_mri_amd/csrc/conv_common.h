@@ -117,23 +117,50 @@ __device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q,
 
 int conv_compute_units();       // kernels_conv.hip
 
-// The epilogue of a tile: y = relu?(acc + skip) for the wave's 32 x 64 outputs (the bias is already in the accumulators).
+// Second half of a tile's epilogue: the wave's 32 pixels x 64 channels lie in `stage` in pixel order (row m = 16 * tile row + column,
+// STR floats apart) and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes: y = relu?(staged + skip).
+// Pixel `it` of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
+// rows below the image are out of the buffer's range (the store is dropped), columns right of it get such an offset.
+template <int STR>
+__device__ __forceinline__ void store_rows32(const ConvArgs& a, const TilePos& q, const float* stage, int wv, int lane, int mt,
+                                             const int pix = CV_C * 4, const int coff = 0) {
+    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
+    const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
+    const int l4 = lane >> 4;
+    const int obase = ((q.y0 + 2 * CV_MT * wv) * a.W + q.x0 + l4) * pix + (lane & 15) * 16;
+    const int wlim = a.W - q.x0 - l4;                            // column 4 (it & 3) valid iff < wlim
+    int off[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * pix : -16;
+    f32x4 sk[8];
+    if (a.skip) {                                                // all eight requests first: one memory round trip, not eight
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const u32x4v k = __builtin_amdgcn_raw_buffer_load_b128(rk, off[it], 0, 0);
+            sk[it] = f32x4{__uint_as_float(k.x), __uint_as_float(k.y), __uint_as_float(k.z), __uint_as_float(k.w)};
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) sk[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * it + l4) * STR + (lane & 15) * 4) + sk[it];
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, off[it], 0, 0);
+    }
+}
+
+// The epilogue of a tile for 32x32 accumulator tiles: y = relu?(acc + skip) for the wave's 32 x 64 outputs (the bias is already in
+// the accumulators).  Accumulator (reg r, lane) = pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32, channel lane & 31
+// (+ 32 for the second tile).  Stored straight from there every lane would issue 32 dword stores per tile, and such a tail is
+// bound by store ISSUE, not by bandwidth: the outputs go through the wave's own 8 KiB of the (now idle) input tile instead.
 __device__ __forceinline__ void store_tile(const ConvArgs& a, const TilePos& q, float* stage, int wv, int lane,
                                            const f32x16 (&acc0)[CV_MT], const f32x16 (&acc1)[CV_MT],
                                            const int pix = CV_C * 4, const int coff = 0) {
     const int i = lane & 31, kh = lane >> 5;
-    // Accumulator (reg r, lane) = pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32, channel
-    // lane & 31 (+ 32 for the second tile).  Stored straight from there every lane would issue 32 dword stores per tile,
-    // and such a tail is bound by store ISSUE, not by bandwidth: the wave's 32 x 64 outputs go through its own 8 KiB of the
-    // (now idle) input tile instead and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes.
-    // The skip input joins there; bias before, ReLU after.
-    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
-    const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
-    // pixel it of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
-    // rows below the image are out of the buffer's range (the store is dropped), columns right of it get such an offset
-    const int l4 = lane >> 4;
-    const int obase = ((q.y0 + 2 * CV_MT * wv) * a.W + q.x0 + l4) * pix + (lane & 15) * 16;
-    const int wlim = a.W - q.x0 - l4;                            // column 4 (it & 3) valid iff < wlim
 #pragma unroll
     for (int mt = 0; mt < CV_MT; ++mt) {
 #pragma unroll
@@ -145,28 +172,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const TilePos& q, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int off[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-            off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * pix : -16;
-        f32x4 sk[8];
-        if (a.skip) {                                            // all eight requests first: one memory round trip, not eight
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const u32x4v k = __builtin_amdgcn_raw_buffer_load_b128(rk, off[it], 0, 0);
-                sk[it] = f32x4{__uint_as_float(k.x), __uint_as_float(k.y), __uint_as_float(k.z), __uint_as_float(k.w)};
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) sk[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * it + l4) * CV_C + (lane & 15) * 4) + sk[it];
-            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(o, ry, off[it], 0, 0);
-        }
+        store_rows32<CV_C>(a, q, stage, wv, lane, mt, pix, coff);
         if (mt + 1 < CV_MT) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -28,6 +28,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr float H3_SCALE = 2048.f, H3_RSCALE = 1.f / 2048.f;
+constexpr int H3_STR = 68;                       // floats between the staging rows of the epilogue
 constexpr int H3_TAP16 = 1024;                   // 16-byte units of one tap's weights: [K step 4][N tile 2][hi, lo][lane 64]
 template <int DIL> struct GeoH {
     static constexpr int LDS = Geo<DIL>::XIN * 4 + 2 * H3_TAP16 * 16;
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     f32x4 (*const wbuf)[H3_TAP16] = reinterpret_cast<f32x4 (*)[H3_TAP16]>(lds + Geo<DIL>::XIN);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, kh = lane >> 5;
-    const int prow = 2 * wv + (i >> 4), pcol = i & 15;          // this lane's pixel of the wave's 32 (tile coordinates)
+    // v_mfma_f32_16x16x32_f16: lane (i, kb) supplies A[row i][k = 8 kb ..] and B[k = 8 kb ..][column i]; the wave's 32 pixels are two
+    // M tiles = its two tile rows (i = the pixel's column), its 64 output channels four N tiles
+    const int i = lane & 15, kb = lane >> 4;
     // C = 64 NC channels: an ITEM is (tile, block cb of 64 output channels), its K loop runs over NC chunks of 64 input channels
     // x 9 taps.  item = tile * NC + cb and gridDim.x is a multiple of NC (launch): a workgroup keeps its cb, so its weight
     // stream -- [cb][chunk][tap] blocks of 16 KiB -- is periodic in 9 NC taps, and on an 8-XCD part every XCD works on NC / 8 ..
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     int item = blockIdx.x;
     if (item >= nitems) return;
     const int cb = item % NC;
-    const float bias0 = a.bias ? a.bias[64 * cb + i] : 0.f, bias1 = a.bias ? a.bias[64 * cb + i + 32] : 0.f;
+    float bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = a.bias ? a.bias[64 * cb + 16 * nt + i] : 0.f;
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.w) + (size_t)cb * period * H3_TAP16 + tid;   // + t * 1024 + 256 j: tap t of the stream
 
     StagingP<DIL> st;
@@ -161,9 +165,11 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
 #pragma unroll 1
     for (; item < nitems; item += gridDim.x) {
         const TilePos q = tile_pos(a, item / NC);
-        f32x16 main0, main1, corr0, corr1;
+        f32x4 mainv[2][4], corrv[2][4];                            // [M tile = tile row of the wave][N tile of 16 channels]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { main0[r] = 0.f; main1[r] = 0.f; corr0[r] = 0.f; corr1[r] = 0.f; }
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { mainv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; corrv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
         for (int cc = 0; cc < NC; ++cc) {
             // the input tile that follows this one -- the tile's next 64 input channels, or the first 64 of the next item -- is
@@ -178,35 +184,38 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
 #endif
             H3_STAMP(1)
             constexpr int PIECE = (Geo<DIL>::XU + 5) / 6;           // the next input tile: requested in six pieces, behind the weights of taps 0..5
-            // One tap = 4 K steps of 6 MFMAs.  What a wave's critical path sees of a tap besides its MFMAs is kept short: the A
-            // operands of step 0 are read BEFORE the barrier (the input tile does not change inside a chunk), only the B reads of
-            // step 0 stand between the barrier and the first MFMA, and the next tap's weights go to LDS (and the request for the
-            // tap after that leaves) behind step 0's MFMAs.
-            h8 ah[2], al[2], bh[2][2], bl[2][2];
-#define H3_LOAD_A(slot, ap_, s_)                                                           \
-            ah[slot] = *reinterpret_cast<const h8*>((ap_) + 32 * (s_));                    \
-            al[slot] = *reinterpret_cast<const h8*>((ap_) + 32 * (s_) + 128);
-#define H3_LOAD_B(slot, s_)                                                                \
-            bh[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 0));        \
-            bl[slot][0] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 1));        \
-            bh[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 2));        \
-            bl[slot][1] = *reinterpret_cast<const h8*>(bp + 1024 * (4 * (s_) + 3));
-#define H3_MFMA(slot)                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
-            main0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bh[slot][0], main0, 0, 0, 0);         \
-            main1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bh[slot][1], main1, 0, 0, 0);         \
-            corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bl[slot][0], corr0, 0, 0, 0);         \
-            corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot], bl[slot][1], corr1, 0, 0, 0);         \
-            corr0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[slot], bh[slot][0], corr0, 0, 0, 0);         \
-            corr1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[slot], bh[slot][1], corr1, 0, 0, 0);         \
+            // One tap = 2 K steps of 32 input channels = 4 half steps (a K step x two of the four N tiles) of 12 MFMAs.  What a
+            // wave's critical path sees of a tap besides its MFMAs is kept short: the A operands of K step 0 are read BEFORE the
+            // barrier (the input tile does not change inside a chunk), only the B reads of half step 0 stand between the barrier
+            // and the first MFMA, and the request for the next tap's weights leaves behind half step 0's MFMAs.
+            h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];                 // [slot][M tile] / [slot][N tile of the pair]
+#define H3_LOAD_A(slot, ap_, s2_)                                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                           \
+                ah[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 64 * (s2_));        \
+                al[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 64 * (s2_) + 128);  \
+            }
+#define H3_LOAD_B(slot, h_)                                                                              \
+            _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                           \
+                bh[slot][q_] = *reinterpret_cast<const h8*>(bp + 1024 * ((((h_) >> 1) * 4 + 2 * ((h_) & 1) + q_) * 2));      \
+                bl[slot][q_] = *reinterpret_cast<const h8*>(bp + 1024 * ((((h_) >> 1) * 4 + 2 * ((h_) & 1) + q_) * 2 + 1));  \
+            }
+#define H3_MFMA(h_)                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                             \
+            _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                           \
+                const int nt_ = 2 * ((h_) & 1) + q_;                                                     \
+                mainv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[((h_) >> 1) & 1][mt], bh[(h_) & 1][q_], mainv[mt][nt_], 0, 0, 0);  \
+                corrv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[((h_) >> 1) & 1][mt], bl[(h_) & 1][q_], corrv[mt][nt_], 0, 0, 0);  \
+                corrv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[((h_) >> 1) & 1][mt], bh[(h_) & 1][q_], corrv[mt][nt_], 0, 0, 0);  \
+            }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);
-            const char* const a0 = reinterpret_cast<const char*>(xin) + (prow * HX + pcol) * (CV_PS * 4) + kh * 16;   // tap (0, 0); + 32 s: K step s; + 128: the lo halves
+            // tap (0, 0), M tile 0: pixel (row 2 w, column i); + HX pixels: M tile 1; + 64 s2: K step; + 128: the lo halves
+            const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + i) * (CV_PS * 4) + kb * 16;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const char* ap = a0 + (ky * DIL * HX + kx * DIL) * (CV_PS * 4);                     // input pixel of this tap
-                const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;          // + 1024 f: fragment f = (2 s + nt) * 2 + part
-                // wbuf[par] (and, at tap 0, the input tile) is complete; every wave is done with wbuf[par ^ 1]
+                const char* bp = reinterpret_cast<const char*>(&wbuf[par][0]) + lane * 16;          // + 1024 f: fragment f = ((s2 * 4 + nt) * 2 + part
                 // this wave's DMA of this tap's weights has landed (the pieces of the input prefetch issued behind it may still be
                 // in flight: a counted wait), its LDS reads are back; then the barrier -- raw: __syncthreads() would drain vmcnt
 #define H3_WAIT_BUT(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory");
@@ -226,7 +235,6 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 H3_STAMP(2)
                 if (tap == 0) { H3_LOAD_A(0, ap, 0) }                 // taps 1..8: read at the end of the tap before
                 H3_LOAD_B(0, 0)
-                H3_LOAD_A(1, ap, 1)
                 H3_LOAD_B(1, 1)
                 H3_MFMA(0)
 #ifndef H3_ABL_NOWWRITE
@@ -242,17 +250,16 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 if (tap == 4) fetch_piece<DIL, 4 * PIECE, 5 * PIECE>(nx, st, xpre);
                 if (tap == 5) fetch_piece<DIL, 5 * PIECE, 6 * PIECE>(nx, st, xpre);
                 H3_STAMP(3)
-                H3_LOAD_A(0, ap, 2)
+                H3_LOAD_A(1, ap, 1)
                 H3_LOAD_B(0, 2)
                 H3_MFMA(1)
-                H3_LOAD_A(1, ap, 3)
                 H3_LOAD_B(1, 3)
-                H3_MFMA(0)
+                H3_MFMA(2)
                 if (tap + 1 < 9) {
                     const int ky1 = (tap + 1) / 3, kx1 = tap + 1 - 3 * ky1;
                     H3_LOAD_A(0, a0 + (ky1 * DIL * HX + kx1 * DIL) * (CV_PS * 4), 0)
                 }
-                H3_MFMA(1)
+                H3_MFMA(3)
                 par ^= 1;
                 H3_STAMP(4)
             }
@@ -262,16 +269,23 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             __syncthreads();                                         // every wave is done with this chunk's input
             H3_STAMP(5)
             if (last) {
-                f32x16 acc0[1], acc1[1];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc0[0][r] = fmaf(corr0[r], H3_RSCALE, main0[r]) + bias0;     // (as initial values of the accumulators the two
-                    acc1[0][r] = fmaf(corr1[r], H3_RSCALE, main1[r]) + bias1;     // biases cost hipcc 32 registers kept across the loop)
-                }
+                // accumulator (reg r, lane (i, kb)) of tile (mt, nt) = pixel (tile row mt of the wave, column 4 kb + r), channel 16 nt + i:
+                // into the wave's staging rows (pixel order, 68 floats apart: the four lane groups of a write start 16 banks apart)
+                float* stage = xin + wv * (32 * H3_STR);
 #ifndef H3_ABL_NOEPI
-                store_tile(a, q, xin + wv * (32 * CV_C), wv, lane, acc0, acc1, pix, 64 * cb);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            stage[(16 * mt + 4 * kb + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]) + bias[nt];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                store_rows32<H3_STR>(a, q, stage, wv, lane, 0, pix, 64 * cb);
 #else
-                if (acc0[0][0] + acc1[0][3] == 123.456f) a.y[tid] = 1.f;
+                if (mainv[0][0][0] + corrv[1][3][3] == 123.456f) a.y[tid] = 1.f;
 #endif
                 H3_STAMP(6)
                 if (more) __syncthreads();                           // every wave is done with the staging area
@@ -303,14 +317,14 @@ __global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Fl
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;      // one (hi, lo) pair per thread
     if (o >= 9LL * C * C) return;
     const int NC = C >> 6;
-    const int j = o & 7, lane = (o >> 3) & 63, nt = (o >> 9) & 1, s = (o >> 10) & 3;
+    const int j = o & 7, lane = (o >> 3) & 63, nt = (o >> 9) & 3, s = (o >> 11) & 1;
     const long long blk = o >> 12;                                // (cb * NC + cc) * 9 + tap
     const int tap = (int)(blk % 9), cc = (int)((blk / 9) % NC), cb = (int)(blk / (9 * NC));
-    const int out = 64 * cb + 32 * nt + (lane & 31), in = 64 * cc + 16 * s + 8 * (lane >> 5) + j;
+    const int out = 64 * cb + 16 * nt + (lane & 15), in = 64 * cc + 32 * s + 8 * (lane >> 4) + j;
     const float w = w_oihw[((size_t)out * C + in) * 9 + tap];
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)((w - (float)hi) * H3_SCALE);
-    const size_t frag = ((size_t)blk * 4 + s) * 4 + nt * 2;      // the hi fragment; lo follows
+    const size_t frag = ((size_t)blk * 2 + s) * 8 + nt * 2;      // the hi fragment; lo follows
     wfrag[(frag * 64 + lane) * 8 + j] = hi;
     wfrag[((frag + 1) * 64 + lane) * 8 + j] = lo;
 }

@@ -126,7 +126,8 @@ def test_conv_kernel_keeps_two_workgroups_per_compute_unit(asm):
 def test_f16x3_conv_kernel_resources(asm):
     """k_conv3x3_c64_h3: at dilation 1 two workgroups share a compute unit -- 81 728 bytes of LDS each (input tile +
     two weight buffers: the 160 KiB exactly), at most 256 registers, no scratch; every matrix instruction is the half form with
-    float32 accumulation, 24 per tap (4 K steps x 2 accumulator halves x 3 products)."""
+    float32 accumulation, 48 per tap (2 K steps of 32 x 2 M tiles x 4 N tiles x 3 products; the nine taps are unrolled), and the
+    weights reach LDS by LDS-DMA (4 per tap and wave + the first tap's)."""
     ks = {n: k for n, k in kernels_of(asm['kernels_conv_f16x3.hip']).items() if 'k_conv3x3_c64_h3' in n}
     assert len(ks) == 4, sorted(ks)
     for n, k in ks.items():
@@ -136,7 +137,8 @@ def test_f16x3_conv_kernel_resources(asm):
         assert i['LDSByteSize'] <= (80 if dil == 1 else 160) * 1024, (n, i)
         assert i['NumVgprs'] + i['NumAgprs'] <= (256 if dil == 1 else 512), (n, i)
         mf = [x for x in k['body'] if x.startswith('v_mfma')]
-        assert len(mf) == 24 and all(x.startswith('v_mfma_f32_32x32x16_f16') for x in mf), (n, len(mf), mf[:2])
+        assert len(mf) == 9 * 48 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf), mf[:2])
+        assert sum(1 for x in k['body'] if x.startswith('global_load_lds_dwordx4')) == 40, n
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():
