@@ -49,22 +49,27 @@ __device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
     for (int e = 0; e < 4; ++e) {
         const _Float16 h = (_Float16)v[e];
         hi[e] = h;
-        lo[e] = (_Float16)((v[e] - (float)h) * H3_SCALE);
+        // (x - h) * 2048 as fma(h, -2048, x * 2048): both forms are exact (the residual has at most 13 significant bits); this one
+        // takes the half as it is (v_fma_mix_f32), no conversion back to float
+        lo[e] = (_Float16)__builtin_fmaf((float)h, -H3_SCALE, v[e] * H3_SCALE);
     }
 }
 
 // Input staging with ONE register per 16-byte chunk (the float32 kernel's Staging<> keeps three; this kernel is at the 256-register
-// line of two workgroups per compute unit): chunk u of thread tid is tile pixel p = (tid >> 4) + 16 u = (row r, column c), channels
+// line of two workgroups per compute unit): chunk u of thread tid is tile pixel p = stage_pixel(tid) + 16 u = (row r, column c), channels
 // 4 (tid & 15) ..; pk[u] = (r W + c) * pix | c -- pix is a multiple of 256, the low byte is free for the column, the only
-// coordinate that needs a test (rows fall out of the buffer range by themselves) -- or -1: no such chunk.
+// coordinate that needs a test (rows fall out of the buffer range by themselves) -- or -1: no such chunk.  (p: stage_pixel below.)
 template <int DIL> struct StagingP { int pk[Geo<DIL>::XU]; };
+// which of the 16 pixels of a chunk row thread tid stages: the two 16-lane groups of a 32-lane half take pixels 8 apart -- 8 x 272
+// bytes = 32 banks: their 8-byte LDS writes (hi and lo halves of four channels) do not collide
+__device__ __forceinline__ int stage_pixel(int tid) { const int g = tid >> 4; return (g >> 1) + 8 * (g & 1); }
 template <int DIL>
 __device__ __forceinline__ void staging_init_p(const ConvArgs& a, int tid, StagingP<DIL>& st, const int pix) {
     constexpr int HX = Geo<DIL>::HX, HY = Geo<DIL>::HY;
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u) {
-        const int p = (tid >> 4) + 16 * u, r = p / HX, c = p - r * HX;
-        st.pk[u] = (tid + CV_THREADS * u < HY * HX * 16) ? (((r * a.W + c) * pix) | c) : -1;
+        const int p = stage_pixel(tid) + 16 * u, r = p / HX, c = p - r * HX;
+        st.pk[u] = (p < HY * HX) ? (((r * a.W + c) * pix) | c) : -1;
     }
 }
 // The request for an input tile is cut into pieces that are issued one per tap: vector-memory results return in order, so a wait for
@@ -99,14 +104,14 @@ __device__ __forceinline__ void fetch_input_p(const ConvArgs& a, const TilePos& 
     fetch_piece<DIL, 0, Geo<DIL>::XU>(f, st, v);
 }
 
-// registers -> LDS tile, split on the way: chunk u of thread tid = 4 consecutive channels cq of tile pixel (tid >> 4) + 16 u --
+// registers -> LDS tile, split on the way: chunk u of thread tid = 4 consecutive channels cq of tile pixel stage_pixel(tid) + 16 u --
 // one base address per thread, the chunks are immediate offsets
 template <int DIL>
 __device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&v)[Geo<DIL>::XU]) {
-    char* px = reinterpret_cast<char*>(xin) + (tid >> 4) * (CV_PS * 4) + 8 * (tid & 15);
+    char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + 8 * (tid & 15);
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u)
-        if (tid + CV_THREADS * u < Geo<DIL>::HY * Geo<DIL>::HX * 16) {
+        if (stage_pixel(tid) + 16 * u < Geo<DIL>::HY * Geo<DIL>::HX) {
             h4 hi, lo;
             split4(v[u], hi, lo);
             *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4)) = hi;
@@ -266,7 +271,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
 #undef H3_LOAD_A
 #undef H3_LOAD_B
 #undef H3_MFMA
-            __syncthreads();                                         // every wave is done with this chunk's input
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every wave is done with this chunk's input (raw barrier: the DMA of
+            __builtin_amdgcn_s_barrier();                            // the next tap's weights stays in flight)
+            asm volatile("" ::: "memory");
             H3_STAMP(5)
             if (last) {
                 // accumulator (reg r, lane (i, kb)) of tile (mt, nt) = pixel (tile row mt of the wave, column 4 kb + r), channel 16 nt + i:
