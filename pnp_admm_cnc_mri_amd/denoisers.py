@@ -270,7 +270,10 @@ class _ResBlock(nn.Module):
 
 
 class UNetRes(nn.Module):
-    """DRUNet: 4 scales, 4 residual blocks each, stride-2 conv down, 2x2 transposed conv up, no bias."""
+    """DRUNet: 4 scales, 4 residual blocks each, stride-2 conv down, 2x2 transposed conv up, no bias.  With a HIP backend the
+    first (2 -> 64) and last (64 -> 1) convolution run on libpnpmri.so's direct kernels as well; the 2 x 2 strided / transposed
+    convolutions between the scales stay with PyTorch."""
+    backend = 'torch'
 
     def __init__(self, in_nc=2, out_nc=1, nc=(64, 128, 256, 512), nb=4):
         super().__init__()
@@ -285,8 +288,27 @@ class UNetRes(nn.Module):
         self.m_up1 = nn.Sequential(nn.ConvTranspose2d(nc[1], nc[0], 2, 2, 0, bias=False), *rb(nc[0]))
         self.m_tail = nn.Conv2d(nc[0], out_nc, 3, 1, 1, bias=False)
 
+    def _hip_ends(self, x0):
+        return (self.backend in HIP_BACKENDS and x0.is_cuda and x0.dtype == torch.float32 and _plain3x3(self.m_head)
+                and self.m_head.in_channels <= 8 and self.m_head.out_channels == 64 and _plain3x3(self.m_tail)
+                and self.m_tail.in_channels == 64 and self.m_tail.out_channels <= 4)
+
     def forward(self, x0):
-        x1 = self.m_head(x0)
+        hip = self._hip_ends(x0)
+        if hip:
+            import ctypes as C
+            from . import _lib
+            L = _lib.lib()
+            stream = C.c_void_p(torch.cuda.current_stream(x0.device).cuda_stream)
+            ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            xc = x0.contiguous()
+            n, _, H, W = xc.shape
+            nhwc = torch.empty((n, H, W, 64), dtype=torch.float32, device=x0.device)
+            _lib.check(L.pnp_conv3x3_head_nhwc(stream, ptr(xc), ptr(_hip_oihw(self, 'head', self.m_head)), ptr(self.m_head.bias), ptr(nhwc),
+                                               n, self.m_head.in_channels, H, W, 0))
+            x1 = nhwc.permute(0, 3, 1, 2)                      # a channels_last NCHW view
+        else:
+            x1 = self.m_head(x0)
         x2 = self.m_down1(x1)
         x3 = self.m_down2(x2)
         x4 = self.m_down3(x3)
@@ -294,7 +316,17 @@ class UNetRes(nn.Module):
         x = self.m_up3(x + x4)
         x = self.m_up2(x + x3)
         x = self.m_up1(x + x2)
-        return self.m_tail(x + x1)
+        x = x + x1
+        if hip:
+            xn = x.permute(0, 2, 3, 1)
+            if not xn.is_contiguous():
+                xn = xn.contiguous()
+            n, H, W, _ = xn.shape
+            out = torch.empty((n, self.m_tail.out_channels, H, W), dtype=torch.float32, device=x.device)
+            _lib.check(L.pnp_conv3x3_tail_nchw(stream, ptr(xn), ptr(_hip_oihw(self, 'tail', self.m_tail)), ptr(self.m_tail.bias), ptr(out),
+                                               n, self.m_tail.out_channels, H, W))
+            return out
+        return self.m_tail(x)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -456,7 +488,7 @@ class Denoiser:
         self.name, self.fam = model_name, family(model_name)
         self.model = model
         self.backend = backend
-        if isinstance(model, _PlainStack):
+        if isinstance(model, (_PlainStack, UNetRes)):
             model.backend = backend
         for m in model.modules():
             if isinstance(m, _ResBlock):
