@@ -222,6 +222,11 @@ int pnp_conv3x3_c64_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float*
 int pnp_conv3x3_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
                            const float* skip_dev, float* y_dev, int n, int C, int H, int W, int relu);
 int pnp_conv3x3_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev, int C);
+/* pnp_conv3x3_tail_nchw (below) in the f16x3 arithmetic: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight (split inside the
+ * kernel), 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias.  On the vector units this layer costs as much as a 64 -> 64 layer of the
+ * f16x3 kernel; as a 16-column matrix product it is bound by reading its input.  Same operand range as above.  New in ABI 9. */
+int pnp_conv3x3_tail_nchw_f16x3(void* hip_stream, const float* x_nhwc_dev, const float* w_oihw_dev, const float* bias_dev,
+                                float* y_nchw_dev, int n, int cout, int H, int W);
 /* First and last layer of the plain stacks (models/network_dncnn.py:52-62, models/network_ffdnet.py:50-56), direct convolutions:
  *   head: x [n][cin][H][W] (NCHW, 1 <= cin <= 8), w a torch Conv2d(cin, 64, 3) weight [64][cin][3][3] -> y [n][H][W][64] (NHWC), + bias, ReLU
  *   tail: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight [cout][64][3][3], 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias

@@ -69,6 +69,7 @@ SIGNATURES = {
     'pnp_conv3x3_c64_pack_f16x3': (C.c_int, [_vp, _vp, _vp]),
     'pnp_conv3x3_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_pack_f16x3': (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    'pnp_conv3x3_tail_nchw_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_head_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_tail_nchw': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_relayout_c64': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -942,6 +942,12 @@ int pnp_conv3x3_tail_nchw(void* stream, const float* x, const float* w, const fl
     HIPCHK(launch_conv3x3_tail((hipStream_t)stream, x, w, bias, y, n, cout, H, W));
     return PNP_OK;
 }
+int pnp_conv3x3_tail_nchw_f16x3(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int cout, int H, int W) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_tail_nchw_f16x3: null pointer");
+    if (n < 1 || H < 1 || W < 1 || cout < 1 || cout > 4) return fail(PNP_E_ARG, "pnp_conv3x3_tail_nchw_f16x3: n, H, W >= 1 and 1 <= cout <= 4 required");
+    HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, w, bias, y, n, cout, H, W));
+    return PNP_OK;
+}
 int pnp_relayout_c64(void* stream, const float* in, float* out, int n, int H, int W, int to_nhwc) {
     if (!in || !out || in == out) return fail(PNP_E_ARG, "pnp_relayout_c64: null or aliased pointers");
     if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_relayout_c64: n, H, W must be >= 1");

@@ -81,6 +81,8 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag,
 hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw /*[C][C][3][3]*/, float* wfrag /*9 C C floats*/, int C);
 hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
                                 float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */);
+hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+                                     int n, int cout, int H, int W);
 hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc);
 hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                                int n, int cin, int H, int W, int relu);

@@ -336,6 +336,97 @@ __global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Fl
     wfrag[((frag + 1) * 64 + lane) * 8 + j] = lo;
 }
 
+// ------------------------------------------------------------------------------------------
+// Last layer of the stacks (64 -> COUT <= 4 channels, NHWC in, NCHW out, + bias; models/network_ffdnet.py:56, network_dncnn.py:62) in
+// the same arithmetic.  On the vector units (kernels_conv.hip: k_conv3x3_tail) this layer costs as much as a body layer of the
+// f16x3 kernel; here it is a 16-column matrix product of which COUT columns are used: per wave two M tiles (its two tile rows) x
+// one N tile, 18 K steps of 32 x 3 products = 108 MFMAs per tile -- the layer is bound by reading its input.  One workgroup per
+// 8 x 16 tile, 58 KiB of LDS (the split input tile + the split weights of COUT channels): two workgroups per compute unit.
+// ------------------------------------------------------------------------------------------
+struct TailH3Args {
+    const float* x; const float* w; const float* bias; float* y;
+    int n, cout, H, W, tiles_x, tiles_y;
+};
+__global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t) {
+    constexpr int HX = Geo<1>::HX;
+    __shared__ __attribute__((aligned(16))) float xin[Geo<1>::XIN];
+    __shared__ __attribute__((aligned(16))) _Float16 wl[9 * 2 * 2 * 4 * 4 * 8];      // [tap][K step][hi, lo][kb][n < 4][8 halves]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kb = lane >> 4;
+    ConvArgs a;                                                   // the staging helpers' view of the input
+    a.x = t.x; a.H = t.H; a.W = t.W; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    const TilePos q = tile_pos(a, blockIdx.x);
+    StagingP<1> st;
+    staging_init_p<1>(a, tid, st, CV_C * 4);
+    f32x4 xpre[Geo<1>::XU];
+    fetch_input_p<1>(a, q, st, xpre, tid, CV_C * 4, 0);
+    // weights: w_oihw [cout][64][3][3] -> split halves in the B operand's order (columns >= cout are zeros the lanes supply themselves)
+    for (int e = tid; e < 9 * 2 * 4 * 4 * 8; e += CV_THREADS) {
+        const int j = e & 7, n = (e >> 3) & 3, kq = (e >> 5) & 3, s2 = (e >> 7) & 1, tap = e >> 8;
+        const float w = n < t.cout ? t.w[((size_t)n * 64 + 32 * s2 + 8 * kq + j) * 9 + tap] : 0.f;
+        const _Float16 hi = (_Float16)w;
+        const int base = (((tap * 2 + s2) * 2) * 4 + kq) * 32 + n * 8 + j;
+        wl[base] = hi;
+        wl[base + 4 * 32] = (_Float16)((w - (float)hi) * H3_SCALE);
+    }
+    put_input_h3<1>(xin, tid, xpre);
+    __syncthreads();
+    f32x4 mainv[2], corrv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { mainv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; corrv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + i) * (CV_PS * 4) + kb * 16;
+    const char* const b0 = reinterpret_cast<const char*>(wl) + kb * 64 + (i & 3) * 16;
+    const bool col = i < t.cout;
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const char* ap = a0 + (ky * HX + kx) * (CV_PS * 4);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            h8 bh = *reinterpret_cast<const h8*>(b0 + ((tap * 2 + s2) * 2) * 256);
+            h8 bl = *reinterpret_cast<const h8*>(b0 + ((tap * 2 + s2) * 2 + 1) * 256);
+            bh = col ? bh : zero; bl = col ? bl : zero;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const h8 ah = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 64 * s2);
+                const h8 al = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 64 * s2 + 128);
+                mainv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, mainv[mt], 0, 0, 0);
+                corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, corrv[mt], 0, 0, 0);
+                corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, corrv[mt], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator (reg r, lane (i, kb)) of M tile mt = pixel (tile row 2 w + mt, column 4 kb + r), output channel i
+    if (col) {
+        const float b = t.bias ? t.bias[i] : 0.f;
+        const size_t plane = (size_t)t.H * t.W;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int gy = q.y0 + 2 * wv + mt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gx = q.x0 + 4 * kb + r;
+                if (gy < t.H && gx < t.W)
+                    t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+            }
+        }
+    }
+}
+
+hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+                                     int n, int cout, int H, int W) {
+    if (cout < 1 || cout > 4 || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    TailH3Args t;
+    t.x = x_nhwc; t.w = w_oihw; t.bias = bias; t.y = y_nchw; t.n = n; t.cout = cout; t.H = H; t.W = W;
+    t.tiles_x = (W + CV_TX - 1) / CV_TX; t.tiles_y = (H + CV_TY - 1) / CV_TY;
+    const long long tiles = (long long)n * t.tiles_x * t.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv3x3_tail_h3, dim3((unsigned)tiles), dim3(CV_THREADS), 0, s, t);
+    return hipGetLastError();
+}
+
 template <int DIL>
 static hipError_t launch_h3_dil(hipStream_t s, const ConvArgs& a, long long items, int cus) {
     // persistent workgroups, a multiple of NC = C / 64 of them (a workgroup keeps its block of output channels); every

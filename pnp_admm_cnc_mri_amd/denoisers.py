@@ -148,8 +148,8 @@ def hip_stack_forward(seq, x, math='f32'):
         if nhwc is not None and _plain3x3(m) and m.in_channels == 64 and m.out_channels <= 4 and not relu:   # tail
             n, H, W, _ = nhwc.shape
             h = torch.empty((n, m.out_channels, H, W), dtype=torch.float32, device=nhwc.device)
-            _lib.check(L.pnp_conv3x3_tail_nchw(stream, ptr(nhwc), ptr(_hip_oihw(seq, k, m)), ptr(m.bias), ptr(h),
-                                               n, m.out_channels, H, W))
+            _lib.check((L.pnp_conv3x3_tail_nchw_f16x3 if math == 'f16x3' else L.pnp_conv3x3_tail_nchw)(
+                stream, ptr(nhwc), ptr(_hip_oihw(seq, k, m)), ptr(m.bias), ptr(h), n, m.out_channels, H, W))
             nhwc = None
             k += 1
             continue
@@ -323,8 +323,8 @@ class UNetRes(nn.Module):
                 xn = xn.contiguous()
             n, H, W, _ = xn.shape
             out = torch.empty((n, self.m_tail.out_channels, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(L.pnp_conv3x3_tail_nchw(stream, ptr(xn), ptr(_hip_oihw(self, 'tail', self.m_tail)), ptr(self.m_tail.bias), ptr(out),
-                                               n, self.m_tail.out_channels, H, W))
+            _lib.check((L.pnp_conv3x3_tail_nchw_f16x3 if self.backend == 'hip_f16x3' else L.pnp_conv3x3_tail_nchw)(
+                stream, ptr(xn), ptr(_hip_oihw(self, 'tail', self.m_tail)), ptr(self.m_tail.bias), ptr(out), n, self.m_tail.out_channels, H, W))
             return out
         return self.m_tail(x)
 

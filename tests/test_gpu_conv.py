@@ -205,13 +205,17 @@ def test_head_and_tail_layers_against_pytorch(env, n, H, W):
         b = torch.randn(cout, device='cuda', generator=g) * 0.1
         for bias in (b, None):
             y = torch.empty(n, cout, H, W, device='cuda')
-            lib.check(L.pnp_conv3x3_tail_nchw(s, p(xn), p(w), p(bias), p(y), n, cout, H, W))
             ref = F.conv2d(xn.permute(0, 3, 1, 2).double(), w.double(), None if bias is None else bias.double(), padding=1)
-            assert _rel(y, ref) <= 2e-6, cout
+            for tail in (L.pnp_conv3x3_tail_nchw, L.pnp_conv3x3_tail_nchw_f16x3):       # vector units; f16x3 on the matrix cores
+                y = torch.full((n, cout, H, W), float('nan'), device='cuda')
+                lib.check(tail(s, p(xn), p(w), p(bias), p(y), n, cout, H, W))
+                assert _rel(y, ref) <= 2e-6, cout
     with pytest.raises(lib.PnpError):
         lib.check(L.pnp_conv3x3_head_nhwc(s, p(xn), p(xn), None, p(xn), n, 9, H, W, 0))       # cin > 8
     with pytest.raises(lib.PnpError):
         lib.check(L.pnp_conv3x3_tail_nchw(s, p(xn), p(xn), None, p(xn), n, 5, H, W))          # cout > 4
+    with pytest.raises(lib.PnpError):
+        lib.check(L.pnp_conv3x3_tail_nchw_f16x3(s, p(xn), p(xn), None, p(xn), n, 5, H, W))
 
 
 @pytest.mark.parametrize('backend', ['hip', 'hip_f16x3'])
