@@ -30,9 +30,9 @@ for k, (v, n) in sorted(acc.items()):
     print('%-30s per launch %.5g  (%d launches)' % (k, v / max(n, 1), n))
 per = lambda k: acc[k][0] / acc[k][1]
 g = per('GRBM_GUI_ACTIVE') / 8
-mf = N * 128 * 4 * 216                      # tiles x waves x MFMAs per wave-tile
-print('# effective clock %.3f GHz (GRBM_GUI_ACTIVE / 8 / duration); v_mfma_f32_32x32x16_f16 issued: %d = %.4g busy cycles at 32 each; counter / (1024 SIMDs x cycles) = %.3f'
-      % (g / dur, mf, 32.0 * mf, per('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * g)))
+mf = N * 128 * 4 * 432                      # tiles x waves x v_mfma_f32_16x16x32_f16 per wave-tile (9 taps x 48)
+print('# effective clock %.3f GHz (GRBM_GUI_ACTIVE / 8 / duration); v_mfma_f32_16x16x32_f16 issued: %d = %.4g busy cycles at 16 each; counter / (1024 SIMDs x cycles) = %.3f'
+      % (g / dur, mf, 16.0 * mf, per('SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * g)))
 rb, wb = 2 * per('FETCH_SIZE') * 1024, per('WRITE_SIZE') * 1024
 alg = N * 16384 * 256
 print('# HBM-side bytes per launch: read %.1f MB (FETCH_SIZE x 2 x 1 KiB), written %.1f MB; algorithmic %.1f MB in + %.1f MB out; (read + written) / duration = %.2f TB/s'
