@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip', 'hip_f16x3'],
                     help="hip = the plain stacks' conv3x3 layers (FFDNet, DnCNN, IRCNN) and DRUNet's 64-channel blocks on libpnpmri.so's "
                          "fp32-MFMA kernel; hip_f16x3 = the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores")
+    ap.add_argument('--cnn-graph', action='store_true', help='replay each denoiser forward (<= cnn-batch slices) from a captured HIP graph')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True for the whole run')
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)))
     ap.add_argument('--rehearse-gloo', action='store_true', help='N > 1 on a box with ONE GPU: gloo backend, all ranks on cuda:0')
@@ -96,7 +97,7 @@ def main():
     if sched:
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
     den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype,
-                     backend=args.cnn_backend).to(dev)
+                     backend=args.cnn_backend, graph=args.cnn_graph).to(dev)
     flop_per_call = D.forward_flops(den, H, W, dev)     # one slice, one D(.)
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)
@@ -165,7 +166,7 @@ def main():
             'dtype': ('f32' if args.cnn_backend != 'hip_f16x3' else 'f32 (conv 64->64: f32 operands as half pairs, exact products, f32 accumulation)') if args.cnn_dtype is None else args.cnn_dtype, 'data': 'synthetic (seeded weights)',
             'config': {'workload': 'PNP_ADMM_CNC_D, %s, %d synthetic %dx%d slices per GPU, %s, S6:569-577 presets'
                                    % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
-                       'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend},
+                       'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend, 'cnn_graph': bool(args.cnn_graph)},
             'slice_iterations_per_s': world * K * B / wall, 'gather_ms': gather_ms,
             'per_rank': None if dist is None else {'ms_per_step': [float(v) / K * 1e3 for v in per_rank[:, 0]],
                                                    'gather_ms': [float(v) for v in per_rank[:, 3]]},

@@ -457,6 +457,7 @@ def forward_flops(den, H, W, device):
 
     hs = [m.register_forward_hook(hook) for m in den.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
     swapped = [(m, m.backend) for m in den.model.modules() if getattr(m, 'backend', None) in HIP_BACKENDS]
+    graph, den.graph = den.graph, False          # nothing of the probe may end up in a captured graph
     for m, _ in swapped:
         m.backend = 'torch'                  # the probe counts module calls; the HIP backend does the same arithmetic outside them
     try:
@@ -466,6 +467,7 @@ def forward_flops(den, H, W, device):
             h.remove()
         for m, b in swapped:
             m.backend = b
+        den.graph = graph
     return 2 * macs[0]
 
 
@@ -474,13 +476,19 @@ class Denoiser:
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
 
     def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
-                 cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch'):
+                 cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch', graph=False):
         """backend: 'torch' (default: the whole forward in PyTorch-ROCm / MIOpen, as the north star keeps it) or 'hip' (the
         64 -> 64 conv3x3 (+ ReLU) layers of DnCNN / FDnCNN / FFDNet / IRCNN (dilations 1..4) and DRUNet's 64-channel residual
         blocks on libpnpmri.so's fp32-MFMA kernel, the plain stacks' first and last layers on its direct kernels; float32 only)
         or 'hip_f16x3' (the same, with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores: float32 operands
         carried as two halves, three exact-product matrix instructions per product, float32 accumulation -- float32-level
         results at several times the float32 matrix rate; operands must lie within the half range, |x| <= 65504)."""
+        # graph=True: a forward of at most `cnn_batch` slices is captured once per input shape into a HIP graph (torch.cuda.CUDAGraph)
+        # and replayed -- for the reference's own usage, ONE slice per call (S6:231), where a forward is a train of 17 .. 70 launches
+        # of a few microseconds each.  Same kernels, same results; re-captured when a parameter changes (load_state_dict).
+        self.graph = bool(graph)
+        self._graphs = {}
+        self._sig_static = None
         if backend not in ('torch',) + HIP_BACKENDS:
             raise ValueError("backend must be 'torch', 'hip' or 'hip_f16x3'")
         if backend in HIP_BACKENDS and cnn_dtype not in (None, 'fp32'):
@@ -546,7 +554,8 @@ class Denoiser:
         if fam == 'drunet':
             if self.x8:
                 x = augment_img_tensor4(x, i % 8)
-            s = self.sigmas[i].float().reshape(1, 1, 1, 1).expand(x.shape[0], 1, x.shape[2], x.shape[3])
+            sig = self.sigmas[i] if self._sig_static is None else self._sig_static     # graph replay: a device scalar refreshed per call
+            s = sig.float().reshape(1, 1, 1, 1).expand(x.shape[0], 1, x.shape[2], x.shape[3])
             x = test_mode(self.model, torch.cat((x, s), dim=1), mode=2, refield=32, min_size=256, modulo=16)
             if self.x8:
                 x = augment_img_tensor4(x, 8 - i % 8 if i % 8 in (3, 5) else i % 8)
@@ -561,11 +570,45 @@ class Denoiser:
         sigma = torch.full((1, 1, 1, 1), self.noise_level_model / 255., dtype=x.dtype, device=x.device)
         return self.model(x, sigma)
 
+    def _graph_ok(self, x):
+        return (self.graph and x.is_cuda and x.shape[0] <= self.cnn_batch and self.cnn_dtype is None and not self.x8
+                and self.bank is None and self.fam in ('dncnn', 'fdncnn', 'ffdnet', 'drunet'))
+
+    def _graph_forward(self, x, i):
+        """replay (capturing first) the HIP graph of `_one` for this input shape"""
+        params = (tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
+                  tuple(getattr(m, 'backend', None) for m in self.model.modules()))      # what the captured launches depend on
+        key = (tuple(x.shape), x.device.index)
+        ent = self._graphs.get(key)
+        if self.fam == 'drunet':
+            if self._sig_static is None:
+                self._sig_static = torch.zeros((), dtype=torch.float32, device=x.device)
+            self._sig_static.copy_(self.sigmas[i])
+        if ent is None or ent[0] != params:
+            static_in = x.clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):                         # warm-up off the capture: weight packing, MIOpen's choices, the allocator
+                for _ in range(2):
+                    self._one(static_in, i)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._one(static_in, i)
+            ent = self._graphs[key] = (params, g, static_in, static_out)
+        _, g, static_in, static_out = ent
+        static_in.copy_(x)
+        g.replay()
+        return static_out
+
     @torch.no_grad()
     def __call__(self, x, i, out=None):
         B = x.shape[0]
         if out is None:
             out = torch.empty_like(x)
+        if self._graph_ok(x):
+            out.copy_(self._graph_forward(x, i))
+            return out
         find = (min(B, self.cnn_batch) >= 16 and x.is_cuda) if self.miopen_find == 'auto' else bool(self.miopen_find)
         if self.backend in HIP_BACKENDS and isinstance(self.model, _PlainStack) and hip_covers_stack(self.model.model):
             find = False                      # no MIOpen call in this forward: the process-global flag is left alone

@@ -25,6 +25,8 @@ save_E=, device=, return_info=  as in solvers.py, plus
                             'hip_f16x3': the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores
                             (float32 operands as two halves, exact products, float32 accumulation: float32-level results,
                             2.3 x the float32 kernel's rate; operands must lie within the half range)
+    cnn_graph=False         True: a denoiser forward of at most cnn_batch slices is captured once per shape into a HIP graph and replayed
+                            (the reference's one-slice calls: a forward is a train of short launches; FFDNet 0.50 -> see DESIGN.md 4.8)
 """
 import os
 
@@ -53,7 +55,7 @@ PRESETS = {
 
 
 def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, device, cnn_dtype=None, miopen_find='auto',
-                cnn_backend='torch'):
+                cnn_backend='torch', cnn_graph=False):
     """The model-zoo switch of S6:129-217: build by name, load weights, eval, no grad, to device."""
     import torch
     net, nlm, scheduled = D.build(model_name)
@@ -80,7 +82,7 @@ def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, d
                                  modelSigma2=nlm * 255., w=1.0)
         sigmas = torch.tensor(s)
     return D.Denoiser(model_name, net, nlm, sigmas=sigmas, noises=noises, x8=x8, bank=bank, cnn_batch=cnn_batch,
-                      cnn_dtype=cnn_dtype, miopen_find=miopen_find, backend=cnn_backend).to(device)
+                      cnn_dtype=cnn_dtype, miopen_find=miopen_find, backend=cnn_backend, graph=cnn_graph).to(device)
 
 
 def _device_state(torch, eng, B, H, W, dev):
@@ -102,7 +104,7 @@ def _finish_pnp(torch, job, eng, x, extra):
 
 def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                    testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
-                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch',
+                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False,
                    **PNP_ADMM_CNC_D_opts):
     """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
     import torch
@@ -114,7 +116,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
     dev = torch.device('cuda', device)
     job = _Job(mask, noises, model_name, 'PNP_ADMM_CNC_D', images, y, mask_id, testsets, testset_name, results,
                save_E, device)
-    den = _load_model(model_name, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend)   # x8 = False, S6:93
+    den = _load_model(model_name, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend, cnn_graph)   # x8 = False, S6:93
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
@@ -137,7 +139,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
 def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
                        testsets='testsets', testset_name='Set1', results='results', save_E=None, device=0,
                        return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
-                       cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='torch', **opts):
+                       cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='torch', cnn_graph=False, **opts):
     """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
     `faithful_model2_path`: the reference loads model_path1 into BOTH nets (S6:435) although it logs
     path 2; True reproduces that, False loads model_name2's own weights."""
@@ -150,11 +152,11 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
     dev = torch.device('cuda', device)
     job = _Job(mask, noises, model_name1 + '_' + model_name2, 'PNP_ADMM_CNC_DnCNN', images, y, mask_id, testsets,
                testset_name, results, save_E, device)
-    den1 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend)
+    den1 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend, cnn_graph)
     if faithful_model2_path and model2 is None:
-        den2 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend)
+        den2 = _load_model(model_name1, model, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend, cnn_graph)
     else:
-        den2 = _load_model(model_name2, model2, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend)
+        den2 = _load_model(model_name2, model2, model_zoo, iter_num, noises, False, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend, cnn_graph)
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
@@ -173,7 +175,7 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
 
 def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                   testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
-                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch',
+                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False,
                   **PNP_ADMM_L1_D_opts):
     """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
     import torch
@@ -184,7 +186,7 @@ def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, t
     x8 = fam in ('drunet', 'ffdnet')                       # x8 = True (S3:87) survives only there (S3:130,142,181)
     job = _Job(mask, noises, model_name, '_' + model_name + '_PNP_ADMM_L1_D', images, y, mask_id, testsets,
                testset_name, results, save_E, device, psnr_fmt='{:.2f}')            # file name S3:308, PSNR format S3:320
-    den = _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend)
+    den = _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, dev, cnn_dtype, miopen_find, cnn_backend, cnn_graph)
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)

@@ -310,3 +310,33 @@ def test_pnp_entry_point_with_the_hip_backend(env, tmp_path, hip):
         res[backend] = np.stack([out[b] for b in range(3)])
     err = np.linalg.norm(res[hip] - res['torch']) / np.linalg.norm(res['torch'])
     assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize('name,backend', [('ffdnet_gray', 'hip_f16x3'), ('ffdnet_gray', 'torch'), ('dncnn_15', 'hip'), ('drunet_gray', 'hip_f16x3')])
+def test_graph_replay_of_a_forward_equals_the_eager_forward(env, name, backend):
+    """`Denoiser(graph=True)`: the forward of one call (the reference's own usage is ONE slice per call, S6:231) captured into a HIP graph
+    and replayed -- the same kernels on the same data: equal results for new inputs, for another iteration's sigma (DRUNet), for
+    another batch size (a second graph), and after the weights changed (re-captured)."""
+    torch, D = env['torch'], env['D']
+    g = torch.Generator(device='cuda').manual_seed(21)
+    noises = (np.random.default_rng(3).standard_normal((256, 256)) + 1j * np.random.default_rng(4).standard_normal((256, 256))) * 5
+    sig = torch.tensor([30.0 / 255, 20.0 / 255, 10.0 / 255]) if name.startswith('drunet') else None
+    net, nlm, _ = D.build(name)
+    net.load_state_dict(D.seeded_state_dict(net, 5))
+    eager = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False).to('cuda')
+    graph = D.Denoiser(name, net, nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False, graph=True).to('cuda')
+    # stacks that run on libpnpmri.so alone replay bit for bit; where MIOpen takes part (the PyTorch backend, DRUNet's strided and
+    # transposed convolutions) it may choose another kernel under capture
+    tol = 0.0 if (backend != 'torch' and not name.startswith('drunet')) else 1e-5
+    for it, B in ((0, 1), (1, 1), (2, 1), (1, 3), (0, 1)):
+        x = torch.rand(B, 1, 256, 256, device='cuda', generator=g)
+        a, b = eager(x, it).clone(), graph(x, it).clone()
+        assert _rel(b, a) <= tol, (it, B, _rel(b, a))
+    assert len(graph._graphs) == 2
+    net.load_state_dict(D.seeded_state_dict(net, 6))             # the graph holds the OLD packed weights: it must be captured again
+    x = torch.rand(1, 1, 256, 256, device='cuda', generator=g)
+    e2 = _rel(graph(x, 0), eager(x, 0))
+    assert e2 <= tol, e2
+    big = D.Denoiser(name, net, nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False, graph=True, cnn_batch=2).to('cuda')
+    x = torch.rand(5, 1, 256, 256, device='cuda', generator=g)   # more slices than one forward takes: the eager path
+    assert _rel(big(x, 0), eager(x, 0)) <= 1e-6 and not big._graphs
