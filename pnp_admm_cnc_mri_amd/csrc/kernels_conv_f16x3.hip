@@ -305,6 +305,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             H3_STAMP(7)
         }
     }
+    // the last tap requested one more block of weights: no wave ends with an LDS-DMA in flight (its LDS may belong to the next
+    // workgroup by the time the data lands)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef H3_PROF
     if (tid == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) g_h3prof[blockIdx.x * 8 + k] = psum[k];
 #endif

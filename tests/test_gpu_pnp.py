@@ -43,13 +43,16 @@ def _psnr_close(x, ref, gt):
     return abs(O.calculate_psnr(np.round(x.astype(np.float64) * 255), gt) - O.calculate_psnr(np.round(ref.astype(np.float64) * 255), gt)) <= 0.01
 
 
+@pytest.mark.parametrize('backend', ['torch', 'hip', 'hip_f16x3'])
 @pytest.mark.parametrize('name', ['ffdnet_gray', 'fdncnn_gray', 'drunet_gray'])
-def test_pnp_admm_cnc_d_golden(env, golden_inputs, name, tmp_path):
+def test_pnp_admm_cnc_d_golden(env, golden_inputs, name, backend, tmp_path):
+    """against the UNMODIFIED reference script's output, with the CNN forward on every backend: PyTorch / MIOpen, the float32-MFMA
+    kernels, the split-half f16 kernels -- the same bar for all three"""
     opts = dict(env['known']['cnc_d_%s_opts' % name])
     opts['iter_num'] = int(opts['iter_num'])
     mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
     out, psnr1 = env['S'].PNP_ADMM_CNC_D(name, mask, golden_inputs['noises'], images=golden_inputs['gray'][None],
-                                         model=_weights(env, name), results=str(tmp_path), **opts)
+                                         model=_weights(env, name), results=str(tmp_path), cnn_backend=backend, **opts)
     ref = env['gold']['cnc_d_' + name]
     assert len(out) == 22 and out[0].shape == (256, 256)
     assert rel_l2(out[0], ref) <= 2e-4, rel_l2(out[0], ref)
