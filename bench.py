@@ -182,6 +182,31 @@ def claim_stdout():
     return real
 
 
+def pnp_record(steps=3, warmup=1, timeout=240):
+    """BASELINE.json configs[2] (PNP_ADMM_CNC_D, FFDNet-gray, 512 slices of 256 x 256, Q_Radial30) measured by bench_pnp.py in two
+    child processes while this one idles: the CNN forward on PyTorch-ROCm / MIOpen (the north star's split) and on libpnpmri.so's
+    split-half f16 matrix-core kernels (`cnn_backend='hip_f16x3'`).  A sub-record: it never fails the main line."""
+    import subprocess
+    rec = {'config': 'configs[2]: PNP_ADMM_CNC_D, FFDNet-gray, 512 x 256x256 slices, Q_Radial30, S6:573 presets (bench_pnp.py --steps %d --warmup %d)'
+                     % (steps, warmup), 'unit': 'it/s (512-slice batches)'}
+    for backend in ('torch', 'hip_f16x3'):
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', 'ffdnet_gray', '--batch', '512', '--steps', str(steps),
+                                  '--warmup', str(warmup), '--cnn-backend', backend], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 timeout=timeout, cwd=ROOT).stdout.decode()
+            j = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+            rec[backend] = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'denoiser_ms_per_step': j['denoiser']['ms_per_step'],
+                            'denoiser_frac_of_fp32_matrix_peak': j['denoiser']['roofline']['frac'], 'x_finite': j['x_finite']}
+        except Exception as e:                                       # noqa: BLE001 -- a failed child is reported, not raised
+            rec[backend] = {'error': repr(e)[:300]}
+    if 'value' in rec.get('torch', {}) and 'value' in rec.get('hip_f16x3', {}):
+        rec['speedup'] = rec['hip_f16x3']['value'] / rec['torch']['value']
+    rec['note'] = ('hip_f16x3: float32 operands carried as two halves, three exact-product f16 matrix instructions per product, float32 '
+                   'accumulation -- per-layer error below the PyTorch / MIOpen float32 kernels\' (tests/test_gpu_conv.py); the fraction is '
+                   'quoted against the float32 matrix peak (157.3 TFLOP/s) and can exceed 1')
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -199,6 +224,8 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)),
                     help='--gpus N without torchrun: seconds after which hanging rank processes are killed (exit 124)')
+    ap.add_argument('--no-pnp-record', action='store_true',
+                    help='skip the `pnp` sub-record (configs[2]: FFDNet PnP on the PyTorch / MIOpen backend and on the f16x3 HIP backend, two child runs of bench_pnp.py, ~40 s)')
     ap.add_argument('--no-f64-record', action='store_true',
                     help="skip the double-precision engine's sub-record (N = 1, headline configuration only)")
     ap.add_argument('--sustain-s', type=float, default=2.0,
@@ -494,6 +521,8 @@ def main():
                                  '(slice-resident path: z, w and the Hermitian half-plane table only, the transposed field never '
                                  'leaves the compute unit; fused path: two real slices per complex FFT, Hermitian half plane).'},
         }
+        if world == 1 and not args.no_cpu_baseline and not args.no_pnp_record and args.size == 256 and args.precision == 'f32':
+            line['pnp'] = pnp_record()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)
             try:
