@@ -339,4 +339,4 @@ def test_graph_replay_of_a_forward_equals_the_eager_forward(env, name, backend):
     assert e2 <= tol, e2
     big = D.Denoiser(name, net, nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False, graph=True, cnn_batch=2).to('cuda')
     x = torch.rand(5, 1, 256, 256, device='cuda', generator=g)   # more slices than one forward takes: the eager path
-    assert _rel(big(x, 0), eager(x, 0)) <= 1e-6 and not big._graphs
+    assert _rel(big(x, 0), eager(x, 0)) <= max(tol, 1e-6) and not big._graphs      # (MIOpen: other kernels for other batch sizes)

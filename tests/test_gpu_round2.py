@@ -72,6 +72,19 @@ def _testset(tmp_path, gray):
     return str(tmp_path / 'testsets'), tmp_path / 'results'
 
 
+def test_bench_pnp_sub_record():
+    """bench.py's `pnp` sub-record (BASELINE.json configs[2] on the PyTorch / MIOpen backend and on the f16x3 HIP backend, two child
+    runs of bench_pnp.py): both children report a finite result, the HIP backend's is the faster one, a failing child would be
+    reported inside the record instead of failing the line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = bench.pnp_record(steps=1, warmup=1)
+    assert set(rec) >= {'config', 'unit', 'torch', 'hip_f16x3', 'speedup', 'note'}, rec
+    for b in ('torch', 'hip_f16x3'):
+        assert 'error' not in rec[b] and rec[b]['x_finite'] and rec[b]['value'] > 0, rec[b]
+    assert rec['speedup'] > 1.5 and rec['hip_f16x3']['denoiser_frac_of_fp32_matrix_peak'] > 1.0, rec
+
+
 def test_file_names_and_log_formats_follow_each_reference_script(env, golden_inputs, tmp_path):
     """S1:138/150 ('_PDG L1', PSNR with 2 decimals), S4:144/155 ('_ADMM CNC', 4 decimals),
     S3:308/320 ('_<model>_PNP_ADMM_L1_D', 2 decimals), S6:320/332 ('PNP_ADMM_CNC_D', 4 decimals, alpha
