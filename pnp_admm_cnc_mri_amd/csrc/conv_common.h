@@ -121,9 +121,11 @@ int conv_compute_units();       // kernels_conv.hip
 // STR floats apart) and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes: y = relu?(staged + skip).
 // Pixel `it` of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
 // rows below the image are out of the buffer's range (the store is dropped), columns right of it get such an offset.
+// bias64 (f16x3 kernel): the 64 biases of this block of output channels, added here -- in the staged order a lane holds four consecutive
+// channels, so the bias is ONE 16-byte value that starts the sum the skip input joins anyway.
 template <int STR>
 __device__ __forceinline__ void store_rows32(const ConvArgs& a, const TilePos& q, const float* stage, int wv, int lane, int mt,
-                                             const int pix = CV_C * 4, const int coff = 0) {
+                                             const int pix = CV_C * 4, const int coff = 0, const float* bias64 = nullptr) {
     const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
     const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
     const int l4 = lane >> 4;
@@ -133,6 +135,7 @@ __device__ __forceinline__ void store_rows32(const ConvArgs& a, const TilePos& q
 #pragma unroll
     for (int it = 0; it < 8; ++it)
         off[it] = (4 * (it & 3) < wlim) ? obase + ((2 * mt + (it >> 2)) * a.W + 4 * (it & 3)) * pix : -16;
+    const f32x4 b4 = bias64 ? *reinterpret_cast<const f32x4*>(bias64 + 4 * (lane & 15)) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 sk[8];
     if (a.skip) {                                                // all eight requests first: one memory round trip, not eight
 #pragma unroll
@@ -140,9 +143,13 @@ __device__ __forceinline__ void store_rows32(const ConvArgs& a, const TilePos& q
             const u32x4v k = __builtin_amdgcn_raw_buffer_load_b128(rk, off[it], 0, 0);
             sk[it] = f32x4{__uint_as_float(k.x), __uint_as_float(k.y), __uint_as_float(k.z), __uint_as_float(k.w)};
         }
+        if (bias64) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) sk[it] += b4;
+        }
     } else {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) sk[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < 8; ++it) sk[it] = b4;
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {

@@ -140,10 +140,6 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     int item = blockIdx.x;
     if (item >= nitems) return;
     const int cb = item % NC;
-    float bias[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bias[nt] = a.bias ? a.bias[64 * cb + 16 * nt + i] : 0.f;
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.w) + (size_t)cb * period * H3_TAP16 + tid;   // + t * 1024 + 256 j: tap t of the stream
 
     StagingP<DIL> st;
     staging_init_p<DIL>(a, tid, st, pix);
@@ -152,10 +148,13 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     // A tap's weights travel global memory -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write): wave w copies
     // units w * 64 + lane + 256 j of the 1024, one tap ahead of their use.  Completion is this wave's vmcnt; visibility to the
     // other waves the barrier after the wait.
+    // (`buffer_load_dwordx4 ... offen lds` with the tap and piece in the SCALAR offset: no vector instruction forms an address)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 9 * a.C * a.C * 4, 0x00020000);
+    const int wvoff = tid * 16, wbase = cb * period * (H3_TAP16 * 16);
 #define H3_DMA(buf_, t_)                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                           \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (t_) * H3_TAP16 + 256 * j), \
-                                         (__attribute__((address_space(3))) void*)(&wbuf[buf_][wv * 64 + 256 * j]), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(&wbuf[buf_][wv * 64 + 256 * j]), 16, wvoff, \
+                                                 wbase + (t_) * (H3_TAP16 * 16) + j * 4096, 0, 0);
     H3_DMA(0, 0)
     put_input_h3<DIL>(xin, tid, xpre);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,11 +285,11 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            stage[(16 * mt + 4 * kb + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]) + bias[nt];
+                            stage[(16 * mt + 4 * kb + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                store_rows32<H3_STR>(a, q, stage, wv, lane, 0, pix, 64 * cb);
+                store_rows32<H3_STR>(a, q, stage, wv, lane, 0, pix, 64 * cb, a.bias ? a.bias + 64 * cb : nullptr);
 #else
                 if (mainv[0][0][0] + corrv[1][3][3] == 123.456f) a.y[tid] = 1.f;
 #endif

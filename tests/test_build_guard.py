@@ -138,7 +138,7 @@ def test_f16x3_conv_kernel_resources(asm):
         assert i['NumVgprs'] + i['NumAgprs'] <= (256 if dil == 1 else 512), (n, i)
         mf = [x for x in k['body'] if x.startswith('v_mfma')]
         assert len(mf) == 9 * 48 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf), mf[:2])
-        assert sum(1 for x in k['body'] if x.startswith('global_load_lds_dwordx4')) == 40, n
+        assert sum(1 for x in k['body'] if x.startswith('buffer_load_dwordx4') and x.split(';')[0].rstrip().endswith(' lds')) == 40, n
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():
