@@ -21,6 +21,7 @@
 // delivers.  Here a tap's weights (64 x 64 x [hi, lo] = 16 KiB, in fragment order) are staged through LDS, double-buffered:
 // requested two taps ahead into registers, written one tap ahead, ONE barrier per tap.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace pnp {
 
@@ -170,12 +171,10 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     for (; item < nitems; item += gridDim.x) {
         const TilePos q = tile_pos(a, item / NC);
         f32x4 mainv[2][4], corrv[2][4];                            // [M tile = tile row of the wave][N tile of 16 channels]
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) { mainv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; corrv[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
-        for (int cc = 0; cc < NC; ++cc) {
+        // One chunk = 64 input channels x 9 taps.  The first chunk of an item is its own instance of the code (FIRST): there the first
+        // MFMA of every accumulator takes the constant 0 as its C operand -- no 64 register moves per item to clear them.
+        auto chunk = [&](const int cc, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             // the input tile that follows this one -- the tile's next 64 input channels, or the first 64 of the next item -- is
             // requested now and consumed after this chunk's nine taps
             const bool last = cc + 1 == NC;
@@ -193,6 +192,7 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             // barrier (the input tile does not change inside a chunk), only the B reads of half step 0 stand between the barrier
             // and the first MFMA, and the request for the next tap's weights leaves behind half step 0's MFMAs.
             h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];                 // [slot][M tile] / [slot][N tile of the pair]
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define H3_LOAD_A(slot, ap_, s2_)                                                                        \
             _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                           \
                 ah[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 64 * (s2_));        \
@@ -208,8 +208,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                             \
             _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                           \
                 const int nt_ = 2 * ((h_) & 1) + q_;                                                     \
-                mainv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[((h_) >> 1) & 1][mt], bh[(h_) & 1][q_], mainv[mt][nt_], 0, 0, 0);  \
-                corrv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[((h_) >> 1) & 1][mt], bl[(h_) & 1][q_], corrv[mt][nt_], 0, 0, 0);  \
+                const bool z_ = FIRST && tap == 0 && (h_) < 2;         /* compile-time: the accumulators' first use */   \
+                mainv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[((h_) >> 1) & 1][mt], bh[(h_) & 1][q_], z_ ? zero4 : mainv[mt][nt_], 0, 0, 0);  \
+                corrv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[((h_) >> 1) & 1][mt], bl[(h_) & 1][q_], z_ ? zero4 : corrv[mt][nt_], 0, 0, 0);  \
                 corrv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[((h_) >> 1) & 1][mt], bh[(h_) & 1][q_], corrv[mt][nt_], 0, 0, 0);  \
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             if (more && xpre[0][0] + xpre[5][1] + xpre[11][2] == 123.456f) a.y[tid] = 2.f;
 #endif
             H3_STAMP(7)
-        }
+        };
+        chunk(0, std::true_type{});
+#pragma unroll 1
+        for (int cc = 1; cc < NC; ++cc) chunk(cc, std::false_type{});
     }
     // the last tap requested one more block of weights: no wave ends with an LDS-DMA in flight (its LDS may belong to the next
     // workgroup by the time the data lands)

@@ -137,8 +137,10 @@ def test_f16x3_conv_kernel_resources(asm):
         assert i['LDSByteSize'] <= (80 if dil == 1 else 160) * 1024, (n, i)
         assert i['NumVgprs'] + i['NumAgprs'] <= (256 if dil == 1 else 512), (n, i)
         mf = [x for x in k['body'] if x.startswith('v_mfma')]
-        assert len(mf) == 9 * 48 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf), mf[:2])
-        assert sum(1 for x in k['body'] if x.startswith('buffer_load_dwordx4') and x.split(';')[0].rstrip().endswith(' lds')) == 40, n
+        # two instances of the chunk code (the first chunk of an item starts its accumulators from a constant-zero C operand)
+        assert len(mf) == 2 * 9 * 48 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf), mf[:2])
+        assert sum(1 for x in mf if x.split(';')[0].rstrip().endswith(', 0')) == 16, n
+        assert sum(1 for x in k['body'] if x.startswith('buffer_load_dwordx4') and x.split(';')[0].rstrip().endswith(' lds')) == 4 + 2 * 36, n
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():
