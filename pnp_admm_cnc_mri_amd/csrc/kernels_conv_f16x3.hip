@@ -46,13 +46,17 @@ __device__ unsigned long long g_h3prof[1024 * 8];
 #endif
 
 __device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (_Float16)v[e];
-        hi[e] = h;
-        // (x - h) * 2048 as fma(h, -2048, x * 2048): both forms are exact (the residual has at most 13 significant bits); this one
-        // takes the half as it is (v_fma_mix_f32), no conversion back to float
-        lo[e] = (_Float16)__builtin_fmaf((float)h, -H3_SCALE, v[e] * H3_SCALE);
+    for (int k = 0; k < 2; ++k) {
+        // two values at a time: ONE packed conversion for the hi halves; (x - h) * 2048 as fma(h, -2048, x * 2048) on the half as it is
+        // (v_fma_mixlo / mixhi_f16) -- both forms are exact: the residual has at most 13 significant bits
+        const f32x2 x = {v[2 * k], v[2 * k + 1]};
+        const h2 h = __builtin_convertvector(x, h2);
+        hi[2 * k] = h[0]; hi[2 * k + 1] = h[1];
+        lo[2 * k] = (_Float16)__builtin_fmaf((float)h[0], -H3_SCALE, x[0] * H3_SCALE);
+        lo[2 * k + 1] = (_Float16)__builtin_fmaf((float)h[1], -H3_SCALE, x[1] * H3_SCALE);
     }
 }
 

@@ -23,6 +23,7 @@ case "$1" in
 build)
   F=$2; NAME=$3; FLAGS=$4
   make -C $C -j4 > /dev/null
+  [ "$F" = kernels_conv_f16x3.hip ] && FLAGS="$FLAGS -fno-slp-vectorize"     # the Makefile's per-file flag
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off $FLAGS -c $C/$F -o $V/${NAME}_${F%.hip}.o
   OBJS=""
   for o in api kernels_generic kernels_fused256 kernels_fused512 kernels_slice256 kernels_conv kernels_conv_f16x3; do
