@@ -1,8 +1,8 @@
-// The 64 -> 64 channel conv3x3 layer of kernels_conv.hip on the HALF-precision matrix cores, float32 results: "f16x3".
+// The conv3x3 layer of kernels_conv.hip (64 -> 64 channels, dilation 1..4) -- and C -> C channels for C = 128 .. 1024 -- on the
+// HALF-precision matrix cores with float32 results: "f16x3".  DESIGN.md 4.8.
 //
-// gfx950 has no float32 matrix instruction faster than its vector units (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD), but
-// v_mfma_f32_32x32x16_f16 runs at 1024 FLOP/clk/SIMD with EXACT products and float32 accumulation.  Every float32 operand is
-// split into two halves,
+// gfx950 has no float32 matrix instruction faster than its vector units (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD), but the f16
+// forms run at 1024 FLOP/clk/SIMD with EXACT products and float32 accumulation.  Every float32 operand is split into two halves,
 //
 //     x = hi + lo / 2048,   hi = half(x),   lo = half((x - hi) * 2048)          (|x - hi - lo / 2048| <= 2^-22 |x|)
 //
@@ -11,15 +11,24 @@
 // 11 significant bits), the accumulation is float32 as in the float32 kernel: the layer's distance from the float64 result
 // is that of the float32 kernel (tests/test_gpu_conv.py measures both).  The factor 2048 keeps `lo` a normal half for every
 // |x| >= 2^-25; operands beyond +-65504 (the half range) turn into infinities -- loudly, not silently.  Three instructions
-// of 16 x the rate: 5.3 x the float32 matrix peak, and the layer becomes a memory-system kernel.
+// of 16 x the rate: 5.3 x the float32 matrix peak on paper; measured 1.9 - 2.6 x, bound by board power.
 //
 // Structure (the float32 kernel's, conv_common.h, where it still fits): persistent 256-thread workgroups, two per compute
-// unit, 8 x 16 output pixels x 64 channels per tile, the input tile (halo included) in LDS for the tile's nine taps -- here
-// already split: a pixel is [64 hi halves][64 lo halves] + 16 bytes, so an operand fragment (8 consecutive channels of a
-// pixel) is one ds_read_b128.  What changes: the float32 kernel streams the weights from L2 into registers, 147 KiB per wave
-// and tile -- at this arithmetic rate that would be 85 bytes per clock and compute unit, more than the vector memory path
-// delivers.  Here a tap's weights (64 x 64 x [hi, lo] = 16 KiB, in fragment order) are staged through LDS, double-buffered:
-// requested two taps ahead into registers, written one tap ahead, ONE barrier per tap.
+// unit, 8 x 16 output pixels x 64 output channels per ITEM, the input tile (halo included) of 64 input channels in LDS for nine
+// taps -- already split: a pixel is [64 hi halves][64 lo halves] + 16 bytes, so an operand fragment (8 consecutive channels of a
+// pixel) is one ds_read_b128.  What differs:
+//   instruction   v_mfma_f32_16x16x32_f16 (the 32x32x16 form does the same arithmetic in the same cycles 7 % slower: under the power
+//                 limit the narrow form holds the higher clock); a wave = 2 M tiles (its two tile rows) x 4 N tiles, main and
+//                 correction accumulators: 64 registers
+//   weights       the float32 kernel streams them from L2 into registers, 147 KiB per wave and tile -- at this arithmetic rate 85
+//                 bytes per clock and compute unit, more than the vector memory path delivers.  Here a tap's 16 KiB (64 x 64 x
+//                 [hi, lo] in fragment order) go through LDS, double-buffered, by LDS-DMA (buffer_load_dwordx4 ... lds, the tap in
+//                 the scalar offset) one tap ahead; a counted s_waitcnt vmcnt and ONE raw s_barrier per tap
+//   C channels    an item's K loop runs over C / 64 chunks of input channels x 9 taps; a workgroup keeps its block of 64 output
+//                 channels, so every XCD's L2 holds the weights of its blocks while the input tiles stream
+//   prefetch      the next input tile is requested in six pieces, one behind each of taps 0..5's DMA (in-order return: a tile
+//                 requested at once would be waited for at the next weight wait), issued unconditionally so that hipcc counts them
+//   first chunk   its own instance of the code: the accumulators start from a constant-zero C operand, not from 64 register moves
 #include "conv_common.h"
 #include <type_traits>
 
@@ -30,12 +39,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr float H3_SCALE = 2048.f, H3_RSCALE = 1.f / 2048.f;
 constexpr int H3_STR = 68;                       // floats between the staging rows of the epilogue
-constexpr int H3_TAP16 = 1024;                   // 16-byte units of one tap's weights: [K step 4][N tile 2][hi, lo][lane 64]
+constexpr int H3_TAP16 = 1024;                   // 16-byte units of one tap's weights: [K step 2][N tile 4][hi, lo][lane 64]
 template <int DIL> struct GeoH {
     static constexpr int LDS = Geo<DIL>::XIN * 4 + 2 * H3_TAP16 * 16;
     static constexpr int WPS = (CV_MT == 1 && LDS <= 80 * 1024) ? 2 : 1;        // 81 728 bytes at dilation 1: two workgroups fill the 160 KiB
 };
-static_assert(CV_MT == 1, "the f16x3 kernel is written for one M tile per wave");
+static_assert(CV_MT == 1, "the f16x3 kernel is written for 8 x 16 pixel tiles (two tile rows per wave)");
 
 #ifdef H3_PROF
 // diagnostic build (profiles/variants.sh build kernels_conv_f16x3.hip h3prof "-DH3_PROF"): shader-clock sums per phase, wave 0 of every workgroup
