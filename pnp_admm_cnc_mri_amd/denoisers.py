@@ -38,10 +38,15 @@ def _conv_stack(in_nc, out_nc, nc, nb, dilations=None):
 
 
 # ----------------------------------------------------------------------------------------------
-# Optional HIP backend of the plain stacks (`Denoiser(backend='hip')`): the 64 -> 64 conv3x3 + ReLU body layers -- 97 % of
-# FFDNet's and DnCNN's arithmetic -- run on libpnpmri.so's fp32-MFMA implicit GEMM (csrc/kernels_conv.hip, 0.78 of the fp32
-# matrix peak at 64 x 64 x 128 x 128 against MIOpen's 0.57) with activations in NHWC; the first and the last layer (1..5 -> 64,
-# 64 -> 1..4 channels) stay with PyTorch.  Same weights, same state_dict; the default backend is PyTorch-ROCm / MIOpen.
+# Optional HIP backends of the denoisers (`Denoiser(backend='hip' | 'hip_f16x3')`): the plain stacks' 64 -> 64 conv3x3 (+ ReLU) layers --
+# 97 % of FFDNet's and DnCNN's arithmetic, IRCNN's dilated ones included -- and DRUNet's residual blocks run on libpnpmri.so with
+# activations in NHWC; the stacks' first (<= 8 -> 64) and last (64 -> <= 4) layers on its direct kernels, so that DnCNN / FDnCNN /
+# FFDNet / IRCNN make no MIOpen call at all.
+#   'hip'        float32 matrix cores (csrc/kernels_conv.hip: 0.77-0.79 of the fp32 matrix peak where MIOpen reaches 0.56-0.59)
+#   'hip_f16x3'  float32 operands as pairs of halves, three exact-product f16 matrix instructions per product, float32 accumulation
+#                (csrc/kernels_conv_f16x3.hip: float32-level error, 1.9-2.6 x the fp32 matrix peak; also DRUNet's 128 / 256 / 512-
+#                channel blocks)
+# Same weights, same state_dict; the default backend is PyTorch-ROCm / MIOpen (the north star's split).
 # ----------------------------------------------------------------------------------------------
 HIP_BACKENDS = ('hip', 'hip_f16x3')       # 'hip': float32 matrix cores; 'hip_f16x3': split-half arithmetic on the f16 matrix cores
 
