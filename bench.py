@@ -17,10 +17,18 @@ kernel (config.path = "slice": a workgroup keeps its slice in registers for all 
 smaller batches, 512x512 and --precision f64 use the two-launch fused kernels ("fused").
 
 Prints ONE JSON line (rank 0).  `value` = 512-slice batch iterations per second summed over
-ranks = slice-iterations/s / 512.  `roofline.achieved` = 57*N_pix*B*K algorithmic bytes
- / HIP-event time of the K iterations on the kernels' own stream.
-`cpu_baseline` = the NumPy oracle (float64, np.fft, 1 thread) on a bounded sample of the same
-slices, rank 0 at N=1 only.
+ranks = slice-iterations/s / 512.  `roofline.achieved` / `roofline.frac` (schema 2, since round 4) =
+the HBM bytes the kernels REALLY move per batched iteration (rocprofv3 PMC of exactly this
+configuration, committed in profiles/traffic.json; the kernel family's own algorithmic bytes
+where no PMC figure exists) / HIP-event time per iteration on the kernels' own stream -- a
+physical fraction of the 8 TB/s peak, <= 1.  `roofline.frac_contract_57N` prices the same time
+against SURVEY.md 8(d)'s 57*N_pix*B bytes (the quantity rounds 1-3 printed under `frac`; it
+exceeds 1 because the kernels move fewer bytes than that formulation).
+Sub-records at N = 1: `sustained` (back-to-back 100-iteration solves), `l1` (configs[0]'s solver,
+ADMM_L1, on the same batch), `f64` (the double-precision engine), `pnp` (configs[2] through
+bench_pnp.py, two child processes after this one has released the GPU), `parity` (three slices of
+the timed run against the NumPy oracle), `cpu_baseline` = the NumPy oracle (float64, np.fft,
+1 thread) on a bounded sample of the same slices.
 """
 import argparse
 import json
@@ -182,28 +190,44 @@ def claim_stdout():
     return real
 
 
-def pnp_record(steps=3, warmup=1, timeout=240):
+def pnp_record(steps=3, warmup=1, total_timeout=300):
     """BASELINE.json configs[2] (PNP_ADMM_CNC_D, FFDNet-gray, 512 slices of 256 x 256, Q_Radial30) measured by bench_pnp.py in two
-    child processes while this one idles: the CNN forward on PyTorch-ROCm / MIOpen (the north star's split) and on libpnpmri.so's
-    split-half f16 matrix-core kernels (`cnn_backend='hip_f16x3'`).  A sub-record: it never fails the main line."""
+    child processes AFTER this process has released its engine and buffers: the CNN forward on PyTorch-ROCm / MIOpen (the north
+    star's split) and on libpnpmri.so's split-half f16 matrix-core kernels (`cnn_backend='hip_f16x3'`).  Each child's
+    line carries its own parity record (three slices of the timed run against the oracle's loop) and its physical roofline (the matrix
+    products really issued against the peak of the pipe that runs them).  A sub-record: it never fails the main line; both children
+    share ONE time budget, and the tail of a failed child's stderr is kept."""
     import subprocess
     rec = {'config': 'configs[2]: PNP_ADMM_CNC_D, FFDNet-gray, 512 x 256x256 slices, Q_Radial30, S6:573 presets (bench_pnp.py --steps %d --warmup %d)'
                      % (steps, warmup), 'unit': 'it/s (512-slice batches)'}
+    deadline = time.monotonic() + total_timeout
     for backend in ('torch', 'hip_f16x3'):
+        err = b''
         try:
-            out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', 'ffdnet_gray', '--batch', '512', '--steps', str(steps),
-                                  '--warmup', str(warmup), '--cnn-backend', backend], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                                 timeout=timeout, cwd=ROOT).stdout.decode()
-            j = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+            left = deadline - time.monotonic()
+            if left < 20:
+                raise TimeoutError('the record\'s time budget of %d s is spent' % total_timeout)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', 'ffdnet_gray', '--batch', '512', '--steps', str(steps),
+                                '--warmup', str(warmup), '--cnn-backend', backend], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=left, cwd=ROOT)
+            err = r.stderr
+            j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
+            rf = j['denoiser']['roofline']
             rec[backend] = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'denoiser_ms_per_step': j['denoiser']['ms_per_step'],
-                            'denoiser_frac_of_fp32_matrix_peak': j['denoiser']['roofline']['frac'], 'x_finite': j['x_finite']}
+                            'denoiser_roofline': {k: rf[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_fp32_equivalent')},
+                            'parity': j['parity'], 'weights': j['config']['weights'],
+                            'x_finite': j['x_finite'], 'denoiser_outputs_finite': j['denoiser_outputs_finite']}
+        except subprocess.TimeoutExpired as e:
+            rec[backend] = {'error': 'timeout', 'stderr_tail': (e.stderr or b'').decode(errors='replace')[-600:]}
         except Exception as e:                                       # noqa: BLE001 -- a failed child is reported, not raised
-            rec[backend] = {'error': repr(e)[:300]}
+            rec[backend] = {'error': repr(e)[:300], 'stderr_tail': err.decode(errors='replace')[-600:]}
     if 'value' in rec.get('torch', {}) and 'value' in rec.get('hip_f16x3', {}):
         rec['speedup'] = rec['hip_f16x3']['value'] / rec['torch']['value']
     rec['note'] = ('hip_f16x3: float32 operands carried as two halves, three exact-product f16 matrix instructions per product, float32 '
-                   'accumulation -- per-layer error below the PyTorch / MIOpen float32 kernels\' (tests/test_gpu_conv.py); the fraction is '
-                   'quoted against the float32 matrix peak (157.3 TFLOP/s) and can exceed 1')
+                   'accumulation -- per-layer error below the PyTorch / MIOpen float32 kernels\' (tests/test_gpu_conv.py).  denoiser_roofline.frac: '
+                   'matrix products really issued (3 per float32 product under hip_f16x3) / time / the peak of the pipe that runs them (dense f16: '
+                   '2.5 PFLOP/s; fp32: 157.3 TFLOP/s); frac_fp32_equivalent prices the float32-equivalent arithmetic against the float32 peak '
+                   'and can exceed 1')
     return rec
 
 
@@ -226,6 +250,8 @@ def main():
                     help='--gpus N without torchrun: seconds after which hanging rank processes are killed (exit 124)')
     ap.add_argument('--no-pnp-record', action='store_true',
                     help='skip the `pnp` sub-record (configs[2]: FFDNet PnP on the PyTorch / MIOpen backend and on the f16x3 HIP backend, two child runs of bench_pnp.py, ~40 s)')
+    ap.add_argument('--no-l1-record', action='store_true',
+                    help="skip the `l1` sub-record (ADMM_L1, configs[0]'s solver with the S1:171 presets, on the same batch; N = 1, headline configuration only)")
     ap.add_argument('--no-f64-record', action='store_true',
                     help="skip the double-precision engine's sub-record (N = 1, headline configuration only)")
     ap.add_argument('--sustain-s', type=float, default=2.0,
@@ -363,6 +389,34 @@ def main():
     if args.sustain_s > 0:
         sus_steps, sus_ms = sustained(eng, args.sustain_s, ev_ms / args.steps)
         sus = [float(sus_steps), float(sus_ms)]
+
+    # `l1` sub-record (N = 1, headline configuration): ADMM_L1 -- the solver of BASELINE.json configs[0], S1:171 presets -- on the
+    # same resident batch: a burst of K steps after W warm-up steps from a fresh state, then the sustained form (half the span).
+    l1_rec = None
+    if (world == 1 and args.solver == 'cnc' and args.size == 256 and args.precision == 'f32' and not args.generic and not args.no_l1_record):
+        def run_l1(e, n):
+            e.admm_l1(n, 0.1, 0.015)
+        eng.init_state()
+        if args.warmup > 0:
+            run_l1(eng, args.warmup)
+        eng.sync()
+        eng.timer_start()
+        run_l1(eng, args.steps)
+        l1_ms = eng.timer_stop()
+        xl = torch.empty((B, H, W), dtype=torch.float32, device='cuda')
+        eng.x(out=xl)
+        eng.sync()
+        l1_rec = {'burst_ms': float(l1_ms), 'path': eng.path_name, 'x': xl}
+        if args.sustain_s > 0:
+            ks = args.sustain_steps
+            per_call = max(l1_ms / args.steps * ks * 1.1, 1e-3)
+            n_heat, n_timed = max(1, int(args.sustain_s * 0.25 * 1e3 / per_call)), max(1, int(args.sustain_s * 0.5 * 1e3 / per_call))
+            for _ in range(n_heat):
+                eng.init_state(); run_l1(eng, ks)
+            eng.timer_start()
+            for _ in range(n_timed):
+                eng.init_state(); run_l1(eng, ks)
+            l1_rec['sus'] = (n_timed * ks, float(eng.timer_stop()))
     if dist is not None:
         from pnp_admm_cnc_mri_amd import sharding
         torch.cuda.synchronize()
@@ -418,6 +472,9 @@ def main():
         def rel(xd):
             return [float(np.linalg.norm(xd[b].double().cpu().numpy() - ref[b]) / np.linalg.norm(ref[b])) for b in picks]
         parity = {'rel_l2_vs_oracle': rel(x_dev), 'slices': picks, 'iterations': n_it, 'oracle': 'oracle/admm_oracle.py (NumPy float64)'}
+        if l1_rec is not None:
+            l1_rec['rel'] = [float(np.linalg.norm(l1_rec['x'][b].double().cpu().numpy() - r) / np.linalg.norm(r))
+                             for b, r in ((b, O.admm_l1(y_all[b].astype(np.complex128), masks[mask_id[b]], n_it, lambda1=0.1, reo=0.015)) for b in picks)]
         if (args.precision == 'f32' and args.size == 256 and args.solver == 'cnc' and not args.generic
                 and not args.no_f64_record):
             e64 = P.Engine(H, W, Bmax=B, device=local_rank, precision='f64')
@@ -482,6 +539,26 @@ def main():
                              'timing': 'HIP events on the kernels\' stream around back-to-back solves { init_state; one call of '
                                        'steps_per_call iterations }, no host sync inside; initialisation inside the span, only iterations '
                                        'counted; N > 1: the slowest rank\'s time per step'}
+        l1_line = None
+        if l1_rec is not None:
+            t_l1 = None
+            try:
+                t_l1 = json.load(open(tpath)).get('%s:l1:%d:f32:b%d' % (l1_rec['path'], H, B), {}).get('hbm_bytes_per_iteration')
+            except Exception:
+                pass
+            own_l1 = OWN_BYTES_PER_PIXEL.get((l1_rec['path'], 'l1'))
+            b_l1 = t_l1 if t_l1 is not None else (None if own_l1 is None else own_l1 * H * W * B)
+            s_burst = l1_rec['burst_ms'] * 1e-3 / K
+            l1_line = {'config': 'ADMM_L1 (S1:171 presets: lambda 0.1, reo 0.015), the same %d resident slices, %s path' % (B, l1_rec['path']),
+                       'value': 1.0 / s_burst * (B / B_PER_GPU), 'unit': 'it/s (512-slice batches)', 'hip_event_ms_per_step': s_burst * 1e3,
+                       'steps': K, 'warmup': args.warmup, 'bytes_per_iteration': b_l1, 'bytes_from': 'pmc' if t_l1 is not None else 'own_algorithmic',
+                       'frac': None if b_l1 is None else b_l1 / s_burst / 1e9 / HBM_PEAK_GBS,
+                       'frac_contract_57N': contract / s_burst / 1e9 / HBM_PEAK_GBS,
+                       'rel_l2_vs_oracle': l1_rec.get('rel'), 'iterations': args.warmup + K}
+            if 'sus' in l1_rec:
+                s_sus = l1_rec['sus'][1] * 1e-3 / l1_rec['sus'][0]
+                l1_line['sustained'] = {'value': 1.0 / s_sus * (B / B_PER_GPU), 'ms_per_step': s_sus * 1e3, 'steps': l1_rec['sus'][0],
+                                        'span_s': l1_rec['sus'][1] * 1e-3, 'frac': None if b_l1 is None else b_l1 / s_sus / 1e9 / HBM_PEAK_GBS}
         line = {
             'metric': 'ADMM iterations/sec on %dx%d complex64 slices (batch=512)' % (H, W),
             'value': value, 'unit': 'it/s (512-slice batches)',
@@ -501,9 +578,10 @@ def main():
             'sustained': sustained_rec,
             'per_rank': per_rank_ms,
             'gather_ms': gather_ms, 'x_checksum': checksum, 'x_finite': finite,
-            'parity': parity, 'f64': f64_record,
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'parity': parity, 'f64': f64_record, 'l1': l1_line,
+            'roofline': {'schema': 2,       # 2 (round 4 on): achieved / frac are PHYSICAL (PMC bytes); rounds 1-3 priced the 57 N contract bytes under the same keys
+                         'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'frac_physical': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'bytes_per_iteration': phys_bytes, 'bytes_from': phys_kind,
                          'frac_own_algorithmic': None if own is None else own / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
                          'own_algorithmic_bytes_per_iteration': own,
@@ -522,6 +600,11 @@ def main():
                                  'leaves the compute unit; fused path: two real slices per complex FFT, Hermitian half plane).'},
         }
         if world == 1 and not args.no_cpu_baseline and not args.no_pnp_record and args.size == 256 and args.precision == 'f32':
+            # the children get the whole card: this process lets go of its engine, its buffers and torch's cached blocks first
+            eng.close()
+            del x_dev
+            l1_rec = None
+            torch.cuda.empty_cache()
             line['pnp'] = pnp_record()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)

@@ -28,7 +28,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MATRIX_PEAK_GFLOPS = 157300.0            # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+F16_MATRIX_PEAK_GFLOPS = 2500000.0           # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
+
+
+def fixture_weights(model_name, net, kind):
+    """'he': He-scaled seeded weights (denoisers.seeded_state_dict, seed 1: the weights of every PnP line of rounds 2-4);
+    'contractive': the fixture weights of the 50-iteration goldens (tests/golden/pnp_known.json: seeds + operator-norm gains), with
+    which D is a contraction, the loop is stable, and the `parity` record below measures the implementation instead of the chaos
+    of an expansive random network.  Same architecture, same arithmetic, same launches either way."""
+    from pnp_admm_cnc_mri_amd import denoisers as D
+    if kind == 'he':
+        return D.seeded_state_dict(net, 1), None
+    meta = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'pnp_known.json')))
+    seed, gains, fam = meta['known50']['seeds'][model_name], meta['gains50'], D.family(model_name)
+    if fam == 'ircnn':
+        bank = {str(i): D.contractive_state_dict(net, fam, seed + i, gains['%s/%d' % (model_name, i)]) for i in range(25)}
+        return bank['0'], bank
+    return D.contractive_state_dict(net, fam, seed, gains[model_name]), None
 
 
 def main():
@@ -49,6 +66,10 @@ def main():
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True for the whole run')
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)))
     ap.add_argument('--rehearse-gloo', action='store_true', help='N > 1 on a box with ONE GPU: gloo backend, all ranks on cuda:0')
+    ap.add_argument('--weights', default='contractive', choices=['contractive', 'he'],
+                    help="seeded synthetic weights: 'contractive' (the 50-iteration goldens' fixture weights: a stable loop, a meaningful "
+                         "parity record) or 'he' (He-scaled random weights: the lines of rounds 2-4)")
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle loop on three slices (N = 1 only; a few CPU seconds)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -91,14 +112,15 @@ def main():
     opts = SP.PRESETS['PNP_ADMM_CNC_D'].get(fam, SP.PRESETS['PNP_ADMM_CNC_DnCNN'])
     dev = torch.device('cuda', local_rank)
     net, nlm, sched = D.build(args.model)
-    net.load_state_dict(D.seeded_state_dict(net, 1))
+    sd, bank = fixture_weights(args.model, net, args.weights)
+    net.load_state_dict(sd)
     iters = args.warmup + args.steps
     sig = None
     if sched:
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
-    den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype,
+    den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], bank=bank, cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype,
                      backend=args.cnn_backend, graph=args.cnn_graph).to(dev)
-    flop_per_call = D.forward_flops(den, H, W, dev)     # one slice, one D(.)
+    flop_per_call, flop_f16x3_part = D.forward_flops(den, H, W, dev, detail=True)     # one slice, one D(.)
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)
     eng.synthesize(img, noise, masks, mask_id)
@@ -108,6 +130,7 @@ def main():
     w = torch.empty_like(z)
     eng.get_state(z, w)
     x, s, t, zn = (torch.empty_like(z) for _ in range(4))
+    den_finite = torch.ones((), dtype=torch.bool, device=dev)      # every denoiser output of the run, BEFORE the clamp, stayed finite
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_dc = t_cnn = 0.0
     t0 = time.perf_counter()
@@ -123,10 +146,12 @@ def main():
             ev[0].record()
             eng.dc_step(z, w, x, opts['reo'])
             ev[1].record()
+            den.select_bank(i)
             den(z, i, out=s)
             eng.cnc_combine(z, x, w, s, t, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
             den(t, i, out=zn)
             ev[2].record()
+            den_finite &= torch.isfinite(s).all() & torch.isfinite(zn).all()
             eng.dual_clamp(x, zn, w)
             ev[3].record()
             z, zn = zn, z
@@ -134,6 +159,29 @@ def main():
             t_dc += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
             t_cnn += ev[1].elapsed_time(ev[2])
         wall = time.perf_counter() - t0              # this rank's clock stops at its own sync, before any collective
+
+    # Checker leg (N = 1): the oracle's PnP loop (float64 NumPy x-update, the reference's marshalling) on three slices of the run that
+    # was just timed, driven by the SAME denoiser object one slice per call -- what differs from the timed run is the HIP x-update /
+    # glue kernels and the batch size of the CNN calls.
+    parity = None
+    if world == 1 and not args.no_parity:
+        from oracle import admm_oracle as O
+        picks = sorted({0, max(B // 2 - 1, 0), B - 1})
+        y_all = eng.download_y()
+
+        def denoise(a, i):
+            den.select_bank(i)
+            tt = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].to(dev)
+            return den(tt, i)[0, 0].cpu().numpy()
+        rels = []
+        with torch.no_grad():
+            for b in picks:
+                ref = O.pnp_admm_cnc(y_all[b].astype(np.complex128), masks[mask_id[b]], denoise, iters, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
+                got = x[b, 0].double().cpu().numpy()
+                rels.append(float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+        parity = {'rel_l2_vs_oracle': rels, 'slices': picks, 'iterations': iters,
+                  'oracle': 'oracle/admm_oracle.py pnp_admm_cnc (NumPy float64 x-update) driven by the same denoiser, one slice per call'}
+        del y_all
 
     gather_ms = None
     if dist is not None:
@@ -158,15 +206,24 @@ def main():
         dc_ms, cnn_ms = t_dc / K, t_cnn / K
         den_flop = 2.0 * flop_per_call * B                              # two D(.) per iteration, every slice
         den_gflops = den_flop / (cnn_ms * 1e-3) / 1e9
+        # What the matrix pipe really ISSUES: under 'hip_f16x3' a float32 product of the C -> C layers (and of the last layer) is three
+        # f16 matrix products, and the roof over those is the dense f16 peak; the remaining layers (the first layer on the vector
+        # units, DRUNet's strided / transposed convolutions) count once.  The float32-equivalent figure stays as frac_fp32_equivalent.
+        f16x3 = args.cnn_backend == 'hip_f16x3'
+        issued_flop = 2.0 * B * (3.0 * flop_f16x3_part + (flop_per_call - flop_f16x3_part)) if f16x3 else den_flop
+        issued_gflops = issued_flop / (cnn_ms * 1e-3) / 1e9
+        den_peak = F16_MATRIX_PEAK_GFLOPS if f16x3 else F32_MATRIX_PEAK_GFLOPS
         alg_bytes = 57.0 * H * W * B
         out.write(json.dumps({
             'metric': 'PNP_ADMM_CNC_D iterations/sec on %dx%d slices (%s)' % (H, W, args.model),
             'value': world * K / wall * (B / 512.0), 'unit': 'it/s (512-slice batches)', 'n_gpus': world, 'steps': K,
             'warmup': args.warmup, 'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'dtype': ('f32' if args.cnn_backend != 'hip_f16x3' else 'f32 (conv 64->64: f32 operands as half pairs, exact products, f32 accumulation)') if args.cnn_dtype is None else args.cnn_dtype, 'data': 'synthetic (seeded weights)',
+            'dtype': ('f32' if args.cnn_backend != 'hip_f16x3' else 'f32 (conv 64->64: f32 operands as half pairs, exact products, f32 accumulation)') if args.cnn_dtype is None else args.cnn_dtype,
+            'data': 'synthetic (seeded %s weights)' % args.weights,
             'config': {'workload': 'PNP_ADMM_CNC_D, %s, %d synthetic %dx%d slices per GPU, %s, S6:569-577 presets'
                                    % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
-                       'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend, 'cnn_graph': bool(args.cnn_graph)},
+                       'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend, 'cnn_graph': bool(args.cnn_graph), 'weights': args.weights},
+            'parity': parity,
             'slice_iterations_per_s': world * K * B / wall, 'gather_ms': gather_ms,
             'per_rank': None if dist is None else {'ms_per_step': [float(v) / K * 1e3 for v in per_rank[:, 0]],
                                                    'gather_ms': [float(v) for v in per_rank[:, 3]]},
@@ -177,12 +234,14 @@ def main():
                                  '57 N bytes per slice-iteration is the contract figure of the whole FFT + prox iteration'},
             'denoiser': {'ms_per_step': cnn_ms, 'share': cnn_ms / (dc_ms + cnn_ms), 'calls_per_step': 2,
                          'flop_per_call_per_slice': flop_per_call, 'flop_per_step': den_flop,
-                         'roofline': {'bound': 'mfma_f32', 'achieved': den_gflops, 'peak': F32_MATRIX_PEAK_GFLOPS, 'unit': 'GFLOP/s',
-                                      'frac': den_gflops / F32_MATRIX_PEAK_GFLOPS},
+                         'roofline': {'bound': 'mfma_f16' if f16x3 else 'mfma_f32', 'achieved': issued_gflops, 'peak': den_peak, 'unit': 'GFLOP/s',
+                                      'frac': issued_gflops / den_peak, 'issued_flop_per_step': issued_flop,
+                                      'achieved_fp32_equivalent': den_gflops, 'frac_fp32_equivalent': den_gflops / F32_MATRIX_PEAK_GFLOPS},
                          'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)' if args.cnn_backend == 'torch' else
                                  'body layers (64 -> 64 conv3x3 + ReLU) on the fp32-MFMA implicit GEMM of libpnpmri.so (kernels_conv.hip); first / last layer on its direct kernels' if args.cnn_backend == 'hip' else
-                                 '64 -> 64 conv3x3 layers in split-half arithmetic on the f16 matrix cores (kernels_conv_f16x3.hip): the fraction is quoted against the FLOAT32 matrix peak and can exceed 1'},
-            'x_finite': bool(torch.isfinite(x).all())}) + '\n')
+                                 'C -> C conv3x3 layers in split-half arithmetic on the f16 matrix cores (kernels_conv_f16x3.hip): roofline = the f16 matrix products really issued (3 per float32 product) against the dense f16 peak; frac_fp32_equivalent prices the float32-equivalent arithmetic against the FLOAT32 matrix peak and can exceed 1'},
+            'x_finite': bool(torch.isfinite(x).all()),
+            'denoiser_outputs_finite': bool(den_finite)}) + '\n')      # taken BEFORE pnp_dual_clamp, every iteration (warm-up included)
         out.flush()
     eng.close()
     if dist is not None:

@@ -81,7 +81,10 @@ int pnp_get_plan(pnp_ctx* ctx, int* queues, int* chunk, int* launches_per_iterat
  * mask_bank: [K][H][W] uint8 in {0,1}, FFT-native layout (CS_MRI/Q_*.mat variable Q1; S4:185).
  * mask_id:   [B] int32 in [0,K): which mask each slice uses (NULL = all slices use mask 0);
  *            validated for host and device inputs alike (PNP_E_ARG when out of range).
- * Replaces the per-image `y`, `index = np.nonzero(mask)` set-up of S4:101-106. */
+ * Replaces the per-image `y`, `index = np.nonzero(mask)` set-up of S4:101-106.
+ * A new problem (this call, pnp_synthesize_problem and their _f64 forms) INVALIDATES the ADMM state and x of the problem before it:
+ * z, w and x are undefined until pnp_init_state, or pnp_set_state with BOTH z and w, has run -- the reference likewise builds z and w
+ * anew per image (S4:103-109). */
 int pnp_upload_problem(pnp_ctx* ctx, const float* y, const uint8_t* mask_bank,
                        const int32_t* mask_id, int B, int K, int on_device);
 
@@ -133,7 +136,8 @@ int pnp_cnc_combine(pnp_ctx* ctx, const float* z_dev, const float* x_dev, const 
                     const float* s_dev, float* t_dev, double alpha, double lambda1, double reo, double b);
 /* t = x + w  (the denoiser input of PNP_ADMM_L1_D, S3:290) */
 int pnp_add(pnp_ctx* ctx, const float* a_dev, const float* b_dev, float* out_dev);
-/* w = w + x - z, then x,z,w <- clamp(.,0,1)                                 (S6:305-308) */
+/* w = w + x - z, then x,z,w <- clamp(.,0,1) with torch.clamp_'s semantics: NaN stays NaN, +-inf go to the bounds, so a
+ * non-finite denoiser output reaches the returned x instead of turning into 0                (S6:305-308) */
 int pnp_dual_clamp(pnp_ctx* ctx, float* x_dev, float* z_dev, float* w_dev);
 
 /* ---- operator API (batched; B slices of the ctx's H x W; complex64 device pointers) ------- */
@@ -205,7 +209,7 @@ int pnp_conv3x3_c64_nhwc(void* hip_stream, const float* x_dev, const float* w_pa
  * per model (again after the weights change). */
 int pnp_conv3x3_c64_pack(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev);
 /* The same layer in SPLIT-HALF arithmetic on the f16 matrix cores ("f16x3"; csrc/kernels_conv_f16x3.hip): every float32 operand
- * is split into two halves, x = hi + lo / 2048, and a product becomes three v_mfma_f32_32x32x16_f16 (hi*hi, hi*lo, lo*hi: exact
+ * is split into two halves, x = hi + lo / 2048, and a product becomes three v_mfma_f32_16x16x32_f16 (hi*hi, hi*lo, lo*hi: exact
  * products, float32 accumulation) -- float32-level results (operands carried to 2^-22, tests/test_gpu_conv.py measures the
  * distance from float64 beside the float32 kernel's) at several times the float32 matrix rate.  Same arguments and semantics as
  * pnp_conv3x3_c64_nhwc; w_packed from pnp_conv3x3_c64_pack_f16x3 (36 864 floats of storage, a different order: the two packings

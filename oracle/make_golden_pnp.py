@@ -95,9 +95,124 @@ def extra():
     print({k: v.shape for k, v in arrays.items()})
 
 
+SEEDS50 = {'drunet_gray': 2000, 'ffdnet_gray': 2001, 'fdncnn_gray': 2002, 'dncnn_15': 2003, 'dncnn_25': 2004, 'ircnn_gray': 2100}   # ircnn: + bank index
+
+
+def fifty():
+    """Round 5: goldens at the reference's OWN run length -- every PnP preset is 50 iterations (S6:569-577, S3:339-347) -- from the
+    unmodified S6 / S3 with CONTRACTIVE seeded weights (denoisers.contractive_state_dict: identity carrier + operator-norm-scaled
+    seeded kernels; the operator norms are measured here by power iteration and committed as `gains50`, so that the GPU box builds
+    bit-identical weights without measuring anything).  Written to tests/golden/pnp50_set1_05.npz + the 'known50' / 'gains50' /
+    'lipschitz50' entries of pnp_known.json; the 3-iteration fixtures stay as they are.
+
+    One more import shim, for the IRCNN branch only: `np.int` (S6:290, S3:281), an alias of the builtin `int` that NumPy 1.24 removed.
+    `np.int = int` restores exactly what the reference was written against; the script itself is not touched."""
+    import contractive as CT
+    MG.install_shims()
+    if not hasattr(np, 'int'):
+        np.int = int
+    d = MG.scratch_dir()
+    os.chdir(d)
+    os.makedirs('model_zoo')
+    torch.set_num_threads(8)
+    kj = os.path.join(MG.GOLD, 'pnp_known.json')
+    meta = json.load(open(kj))
+    gains, lips = {}, {}
+    gold_in = np.load(os.path.join(MG.GOLD, 'inputs_set1_05.npz'))
+    for n, seed in SEEDS50.items():
+        net, nlm, sched = D.build(n)
+        fam = D.family(n)
+        if fam == 'ircnn':                                    # the 25-model bank, S6:196: {str(index): state_dict}
+            bank = {}
+            for idx in range(25):
+                g = CT.conv_operator_norms(net, seed + idx)
+                gains['%s/%d' % (n, idx)] = g
+                bank[str(idx)] = D.contractive_state_dict(net, fam, seed + idx, g)
+            torch.save(bank, os.path.join('model_zoo', n + '.pth'))
+            sd = bank['24']
+        else:
+            gains[n] = CT.conv_operator_norms(net, seed)
+            sd = D.contractive_state_dict(net, fam, seed, gains[n])
+            torch.save(sd, os.path.join('model_zoo', n + '.pth'))
+        # local Lipschitz constant of the denoiser map at the loop's starting point (recorded, not asserted)
+        net.load_state_dict(sd)
+        net.eval()
+        for p_ in net.parameters():
+            p_.requires_grad = False
+        sig = torch.tensor(MG_sigmas(nlm, 50)) if sched else None
+        den = D.Denoiser(n, net, nlm, sigmas=sig, noises=gold_in['noises_c128'] * 3.0)
+        mask0 = np.unpackbits(gold_in['Q_Random30_packbits'])[:65536].reshape(256, 256).astype(np.float64)
+        y0 = np.fft.fft2(np.float32(gold_in['gray_u8'] / 255.)) * mask0 + gold_in['noises_c128'] * 3.0
+        x0 = torch.from_numpy(np.abs(np.fft.ifft2(y0)).astype(np.float32))[None, None]
+        lips[n] = CT.lipschitz_at(lambda t: den._one(t, 0), x0, iters=10)
+        print(n, 'Lipschitz at x0 ~ %.4f' % lips[n], flush=True)
+
+    arrays, known = {}, {'numpy': np.__version__, 'torch': torch.__version__, 'iters': 50, 'seeds': SEEDS50,
+                         'note': 'x after the presets\' own 50 iterations, 05.png, committed presets, contractive seeded weights; '
+                                 'mask Q_Random30 unless the key names another'}
+
+    def line(lines):
+        return [l for l in lines if 'PSNR' in l and '05.png' in l][-1]
+
+    def fopts(o):
+        return {k: float(v) for k, v in o.items()}
+
+    # ---- S6: its main runs drunet_gray (CNC_D) and the dncnn_25 / dncnn_15 pair at the presets -------------------------------
+    g, lines, _ = MG.run_script(S6, [], 'Set1_dn_drunet_gray')
+    arrays['cnc_d_drunet_gray'] = np.asarray(g['out1'], np.float32)
+    arrays['cnc_dncnn_pair'] = np.asarray(g['out2'], np.float32)
+    known['cnc_d_drunet_gray'] = line(lines)
+    known['cnc_d_drunet_gray_opts'] = fopts(g['PNP_ADMM_CNC_D_opts4'])
+    known['cnc_dncnn_pair_opts'] = fopts(g['PNP_ADMM_CNC_DnCNN_opts'])
+    assert int(g['PNP_ADMM_CNC_D_opts4']['iter_num']) == 50
+    jobs6 = [('fdncnn_gray', 0, 'PNP_ADMM_CNC_D_opts1', 'cnc_d_fdncnn_gray'), ('ffdnet_gray', 0, 'PNP_ADMM_CNC_D_opts2', 'cnc_d_ffdnet_gray'),
+             ('ircnn_gray', 0, 'PNP_ADMM_CNC_D_opts3', 'cnc_d_ircnn_gray'),
+             ('ffdnet_gray', 1, 'PNP_ADMM_CNC_D_opts2', 'cnc_d_ffdnet_gray_radial30'),         # BASELINE.json configs[2]: FFDNet, Q_Radial30
+             ('drunet_gray', 2, 'PNP_ADMM_CNC_D_opts4', 'cnc_d_drunet_gray_cartesian30')]      # configs[3]: DRUNet, Q_Cartesian30
+    for n, k, on, tag in jobs6:
+        cap = MG._Capture('Set1_dn_' + n)
+        with contextlib.redirect_stdout(io.StringIO()):
+            o, _ = g['PNP_ADMM_CNC_D'](n, g['mask'][k], g['noises'], **g[on])
+        arrays[tag] = np.asarray(o[0], np.float32)
+        known[tag] = line(cap.lines)
+        known[tag + '_opts'] = fopts(g[on])
+        print(tag, known[tag], flush=True)
+
+    # ---- S3: its main runs drunet_gray (x8 cycle) -----------------------------------------------------------------------------
+    g, lines, _ = MG.run_script(S3, [], 'Set1_dn_drunet_gray')
+    arrays['l1_d_drunet_gray'] = np.asarray(g['out'][0], np.float32)
+    known['l1_d_drunet_gray'] = line(lines)
+    known['l1_d_drunet_gray_opts'] = fopts(g['PNP_ADMM_L1_D_opts5'])
+    for n, on in (('fdncnn_gray', 'PNP_ADMM_L1_D_opts1'), ('dncnn_15', 'PNP_ADMM_L1_D_opts2'), ('ffdnet_gray', 'PNP_ADMM_L1_D_opts3'),
+                  ('ircnn_gray', 'PNP_ADMM_L1_D_opts4')):
+        cap = MG._Capture('Set1_dn_' + n)
+        with contextlib.redirect_stdout(io.StringIO()):
+            o = g['PNP_ADMM_L1_D'](n, g['mask'][0], g['noises'], **g[on])
+        arrays['l1_d_' + n] = np.asarray(o[0], np.float32)
+        known['l1_d_' + n] = line(cap.lines)
+        known['l1_d_' + n + '_opts'] = fopts(g[on])
+        print('l1_d_' + n, known['l1_d_' + n], flush=True)
+
+    for k, v in arrays.items():
+        assert v.shape == (256, 256) and np.isfinite(v).all(), k
+        known[k + '_sum'] = float(v.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(MG.GOLD, 'pnp50_set1_05.npz'), **arrays)
+    meta['known50'], meta['gains50'], meta['lipschitz50'] = known, gains, lips
+    with open(kj, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(known, indent=1, sort_keys=True))
+
+
+def MG_sigmas(nlm, iters):
+    from pnp_admm_cnc_mri_amd import utils_pnp
+    return utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1]
+
+
 def main():
     if '--extra' in sys.argv:
         return extra()
+    if '--fifty' in sys.argv:
+        return fifty()
     MG.install_shims()
     d = MG.scratch_dir()
     os.chdir(d)

@@ -406,8 +406,10 @@ static int prepare_fused_tables(pnp_ctx* c) {
 int pnp_upload_problem(pnp_ctx* c, const float* y, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
     CTX(c); F32_ONLY(c);
     if (!y) return fail(PNP_E_ARG, "pnp_upload_problem: y is null");
-    // (the state keeps whatever order it is in: a new problem does not read it, and pnp_init_state / pnp_set_state / the next
-    // loop convert or overwrite it when they need to -- no conversion kernels on the upload path)
+    // A new problem invalidates the state (include/pnp_mri.h): z / w are UNDEFINED until pnp_init_state or pnp_set_state(z, w).  The
+    // order flag is reset with it -- a conversion under the new B would read the slice path's padded arrays beyond the old batch.
+    c->state_sliced = false;
+    c->have_x = false;
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     rc = copy_in(c, c->y, y, (size_t)B * c->N * sizeof(float2), on_device);
@@ -419,8 +421,10 @@ int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int
                            const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
     CTX(c); F32_ONLY(c);
     if (!img || !noise) return fail(PNP_E_ARG, "pnp_synthesize_problem: img/noise is null");
-    // (the state keeps whatever order it is in: a new problem does not read it, and pnp_init_state / pnp_set_state / the next
-    // loop convert or overwrite it when they need to -- no conversion kernels on the upload path)
+    // A new problem invalidates the state (include/pnp_mri.h): z / w are UNDEFINED until pnp_init_state or pnp_set_state(z, w).  The
+    // order flag is reset with it -- a conversion under the new B would read the slice path's padded arrays beyond the old batch.
+    c->state_sliced = false;
+    c->have_x = false;
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     const size_t img_bytes = (size_t)B * c->N * sizeof(float);

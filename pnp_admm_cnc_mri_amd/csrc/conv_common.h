@@ -117,6 +117,10 @@ __device__ __forceinline__ void fetch_input(const ConvArgs& a, const TilePos& q,
 
 int conv_compute_units();       // kernels_conv.hip
 
+// torch.nn.ReLU: NaN in -> NaN out (fmaxf is IEEE maxNum and would return the 0).  A non-finite activation -- an operand of the f16x3
+// kernel beyond the half range, say -- must stay visible through every following layer and the solver's clamp (S6:306-308).
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+
 // Second half of a tile's epilogue: the wave's 32 pixels x 64 channels lie in `stage` in pixel order (row m = 16 * tile row + column,
 // STR floats apart) and leave as EIGHT 16-byte stores per lane, a whole 256-byte pixel per 16 lanes: y = relu?(staged + skip).
 // Pixel `it` of this lane's eight: tile row 2 MT w + 2 mt + (it >> 2), column 4 (it & 3) + (lane >> 4), channels 4 (lane & 15) ..;
@@ -154,7 +158,7 @@ __device__ __forceinline__ void store_rows32(const ConvArgs& a, const TilePos& q
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * it + l4) * STR + (lane & 15) * 4) + sk[it];
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.relu) { v[0] = relu_keep_nan(v[0]); v[1] = relu_keep_nan(v[1]); v[2] = relu_keep_nan(v[2]); v[3] = relu_keep_nan(v[3]); }
         const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
         __builtin_amdgcn_raw_buffer_store_b128(o, ry, off[it], 0, 0);
     }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_head(HeadArgs a) {
     for (int px = 0; px < 8; ++px) {
         const int gx = x0 + col0 + px;
         f32x4 v = acc[px];
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.relu) { v[0] = relu_keep_nan(v[0]); v[1] = relu_keep_nan(v[1]); v[2] = relu_keep_nan(v[2]); v[3] = relu_keep_nan(v[3]); }
         const int off = (gx < a.W) ? (gy * a.W + gx) * (CV_C * 4) + cq * 16 : -16;        // rows below the image: out of range, dropped
         const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
         __builtin_amdgcn_raw_buffer_store_b128(o, ry, off, 0, 0);

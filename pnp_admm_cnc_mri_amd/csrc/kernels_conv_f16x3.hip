@@ -14,7 +14,7 @@
 // of 16 x the rate: 5.3 x the float32 matrix peak on paper; measured 1.9 - 2.6 x, bound by board power.
 //
 // Structure (the float32 kernel's, conv_common.h, where it still fits): persistent 256-thread workgroups, two per compute
-// unit, 8 x 16 output pixels x 64 output channels per ITEM, the input tile (halo included) of 64 input channels in LDS for nine
+// unit at dilation 1 (80 KiB of LDS each; one at dilations 2..4: 98 .. 137 KiB), 8 x 16 output pixels x 64 output channels per ITEM, the input tile (halo included) of 64 input channels in LDS for nine
 // taps -- already split: a pixel is [64 hi halves][64 lo halves] + 16 bytes, so an operand fragment (8 consecutive channels of a
 // pixel) is one ds_read_b128.  What differs:
 //   instruction   v_mfma_f32_16x16x32_f16 (the 32x32x16 form does the same arithmetic in the same cycles 7 % slower: under the power
@@ -258,6 +258,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
 #ifndef H3_ABL_NOWWRITE
                 H3_DMA(par ^ 1, t1)                                  // the next tap's weights
 #endif
+                // the counted wait of the next tap (vmcnt = the piece's loads) is right only if the four DMAs are OLDER than the piece:
+                // pin the order (the two groups do not alias, hipcc is otherwise free to interleave them); tools/isa_scan.py checks it
+                __builtin_amdgcn_sched_barrier(0);
 #ifndef H3_ABL_WSAME
                 t1 = t1 + 1 == period ? 0 : t1 + 1;
 #endif
@@ -336,8 +339,8 @@ extern "C" int pnp_conv_h3_prof_read(unsigned long long* out /* [1024][8] */) {
 #endif
 
 // torch.nn.Conv2d weight [C out][C in][3][3] -> split halves in fragment order, blocks [cb][chunk cc][tap] of 16 KiB: half j of lane
-// (n, kb) of fragment (K step s, N tile nt, part) is part(W[out = 64 cb + 32 nt + n][in = 64 cc + 16 s + 8 kb + j][tap]) --
-// v_mfma_f32_32x32x16_f16: lane l supplies B[k = 8 (l >> 5) + j][column l & 31]; the A side reads input channels in the same
+// (n, kb) of fragment (K step s, N tile nt, part) is part(W[out = 64 cb + 16 nt + n][in = 64 cc + 32 s + 8 kb + j][tap]) --
+// v_mfma_f32_16x16x32_f16: lane l supplies B[k = 8 (l >> 4) + j][column l & 15]; the A side reads input channels in the same
 // order.  As many bytes as the float32 weights.  Once per model.
 __global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Float16* wfrag, int C) {
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;      // one (hi, lo) pair per thread

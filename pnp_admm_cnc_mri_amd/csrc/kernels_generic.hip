@@ -652,7 +652,9 @@ template hipError_t launch_cols<double>(hipStream_t, int, int, bool, ColMid, boo
 // ------------------------------------------------------------------------------------------
 // pointwise kernels on caller pointers (PnP path, S6:301-308): 4 floats per lane, grid-stride
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+// torch's clamp_(0, 1) (S6:306-308): NaN in -> NaN out.  fminf / fmaxf alone are IEEE minNum / maxNum and return the OTHER operand for a
+// NaN -- a non-finite denoiser output would turn into 0 here and the loop would carry on with plausible numbers.
+__device__ __forceinline__ float clamp01(float v) { return v != v ? v : fminf(fmaxf(v, 0.0f), 1.0f); }
 
 template <bool CNC>
 __global__ __launch_bounds__(256) void k_prox(const float4* x, float4* z, float4* w, ProxParams p, size_t n4) {

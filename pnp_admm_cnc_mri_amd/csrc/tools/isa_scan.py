@@ -87,12 +87,48 @@ def store_hazards(body, window=2):
     return bad
 
 
+def dma_order_violations(body, group=4):
+    """LDS-DMA ordering of the f16x3 convolution kernels (kernels_conv_f16x3.hip): a tap's weights are written into LDS by
+    `buffer_load_dwordx4 ... lds` (D below) and published to the other waves by `s_waitcnt vmcnt(n)` + `s_barrier`, where n counts the
+    plain loads / stores (L) issued BEHIND the DMAs that may stay in flight.  That count is right only while every D of a group is
+    older than those L: vector-memory operations complete in order, so `vmcnt(n)` retires everything but the youngest n.  The walk
+    keeps the operations that may still be in flight (a wait truncates the list to its youngest n), calls a barrier CLEAN when no D is
+    among them, and reports (a) a new group of D issued although no clean barrier followed the group before it -- a buffer would be
+    overwritten, or read, with its DMA unfinished -- and (b) a kernel that ends (s_endpgm) with a D possibly in flight.  A plain access
+    that slips between or in front of a group's DMAs with a counted wait behind it leaves a D among the youngest n: the barrier is not
+    clean and (a) fires at the next group.  The walk is over the linear instruction order (loops are not followed)."""
+    bad, inflight, dirty, run = [], [], False, 0
+    for idx, ins in enumerate(body):
+        if ins.startswith(('buffer_load', 'buffer_store', 'global_load', 'global_store', 'flat_load', 'flat_store', 'buffer_atomic', 'global_atomic')):
+            d = ins.startswith('buffer_load') and ins.rstrip().endswith(' lds')
+            if d:
+                if run % group == 0 and dirty:
+                    bad.append((idx, 'LDS-DMA group issued before the group before it was published by a clean barrier', ins))
+                run += 1
+                if run % group == 0:
+                    dirty = True
+            inflight.append('D' if d else 'L')
+            continue
+        m = re.match(r's_waitcnt\b.*vmcnt\((\d+)\)', ins)
+        if m:
+            n = int(m.group(1))
+            inflight = inflight[len(inflight) - n:] if n else []
+        elif ins.startswith('s_barrier'):
+            if 'D' not in inflight:
+                dirty = False
+        elif ins.startswith('s_endpgm') and 'D' in inflight:
+            bad.append((idx, 'wave may end with an LDS-DMA in flight', ins))
+    return bad
+
+
 def scan_text(text):
     """[(kernel, store, overwriting instruction)] of one assembly file, and the number of wide buffer stores seen."""
     bad, n = [], 0
     for name, k in kernels_of(text).items():
         n += sum(1 for ins in k['body'] if re.match(r'buffer_store_dwordx[34]', ins))
         bad += [(name, a, b) for a, b in store_hazards(k['body'])]
+        if '_h3' in name and any(ins.startswith('buffer_load') and ins.rstrip().endswith(' lds') for ins in k['body']):
+            bad += [(name, 'LDS-DMA order: ' + why, ins) for _, why, ins in dma_order_violations(k['body'])]
     return bad, n
 
 
@@ -102,7 +138,7 @@ def main(paths):
         bad, n = scan_text(open(p).read())
         total += n
         for name, a, b in bad:
-            sys.stderr.write('%s: %s: wide buffer store with an SGPR soffset overwritten inside its hazard window:\n    %s\n    %s\n' % (p, name, a, b))
+            sys.stderr.write('%s: %s: %s:\n    %s\n    %s\n' % (p, name, 'hazard' if a.startswith('LDS-DMA') else 'wide buffer store with an SGPR soffset overwritten inside its hazard window', a, b))
             rc = 1
     sys.stderr.write('isa_scan: %d wide buffer stores in %d file(s): %s\n' % (total, len(paths), 'HAZARD' if rc else 'ok'))
     return rc

@@ -385,6 +385,77 @@ def seeded_state_dict(module, seed=0, gain=1.0):
     return out
 
 
+# Contractive synthetic weights (parity fixtures at the reference's own 50 iterations, tests/golden/pnp50_*).  He-scaled random nets
+# are expansive: two float32 implementations of the same PnP loop drift 1e-2 apart in 50 iterations, which says nothing about
+# either.  Here every convolution is  W = a P + (eps / sigma) R:  P the centre-tap identity on the channels both sides share
+# (image channels -> the same-numbered feature channels in the first layer, all C channels in a C -> C layer, the first out_nc
+# channels in the last), R standard normal from the seeded per-key generator, sigma = the operator norm of conv(R) (power
+# iteration, measured ONCE by oracle/make_golden_pnp.py and committed in tests/golden/pnp_known.json so that every machine builds
+# bit-identical weights).  Each layer is then (a + eps)-Lipschitz, every feature channel carries O(1) activations through the
+# whole depth, and the map of the network is  a_last x + (a few per cent of seeded features):  a denoiser-like contraction.
+_CONTRACTIVE = {          # role -> (a, eps); 'tail' a is per family below
+    'head': (1.0, 0.5), 'body': (1.0, 0.01), 'res0': (0.0, 1.0), 'res2': (0.0, 0.02), 'down': (0.0, 0.5), 'up': (0.0, 0.5), 'tail': (None, 0.01)}
+# x - n(x) families: n ~ 0.15 x.  Direct maps: 0.6 .. 0.7 -- with 0.85 the reference's own PNP_ADMM_L1_D loop (clamps on x, z AND w,
+# S3:293-296) grows a pixel-local oscillation in dark regions from iteration ~35 on (profiles/experiments/contractive_sens.py): a property
+# of that loop, not of an implementation, but a fixture must not sit on it
+_CONTRACTIVE_TAIL = {'dncnn': 0.15, 'ircnn': 0.15, 'fdncnn': 0.7, 'ffdnet': 0.6, 'drunet': 0.6}
+
+
+def contractive_roles(module):
+    """{state_dict weight key: role} for the five architectures (see _CONTRACTIVE)."""
+    keys = [k for k in module.state_dict() if k.endswith('weight')]
+    roles = {}
+    if isinstance(module, UNetRes):
+        for k in keys:
+            if k == 'm_head.weight':
+                roles[k] = 'head'
+            elif k == 'm_tail.weight':
+                roles[k] = 'tail'
+            elif '.res.0.' in k:
+                roles[k] = 'res0'
+            elif '.res.2.' in k:
+                roles[k] = 'res2'
+            elif k.startswith('m_down'):
+                roles[k] = 'down'
+            elif k.startswith('m_up'):
+                roles[k] = 'up'
+            else:
+                raise ValueError(k)
+    else:
+        for n, k in enumerate(keys):
+            roles[k] = 'head' if n == 0 else 'tail' if n == len(keys) - 1 else 'body'
+    return roles
+
+
+def contractive_state_dict(module, fam, seed, gains):
+    """Deterministic CONTRACTIVE weights (comment above).  `gains`: {weight key: operator norm of the conv with the seeded standard-
+    normal kernel R} as committed in tests/golden/pnp_known.json ('gains50'); a pure function of (architecture, family, seed, gains)."""
+    sd = module.state_dict()
+    roles = contractive_roles(module)
+    n_img = 4 if fam == 'ffdnet' else 1
+    out = {}
+    for k, v in sd.items():
+        h = int.from_bytes(hashlib.sha256(('%d:%s' % (seed, k)).encode()).digest()[:8], 'little')
+        rng = np.random.default_rng(h)
+        if not k.endswith('weight'):
+            out[k] = torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32) * np.float32(0.01))
+            continue
+        role = roles[k]
+        a, eps = _CONTRACTIVE[role]
+        if role == 'tail':
+            a = _CONTRACTIVE_TAIL[fam]
+        r = rng.standard_normal(tuple(v.shape))                     # float64
+        wgt = r * (eps / float(gains[k]))
+        if a:
+            co, ci = v.shape[0], v.shape[1]
+            n = n_img if role == 'head' else co if role == 'tail' else min(co, ci)
+            ctr = (v.shape[2] // 2, v.shape[3] // 2)
+            for c in range(min(n, co, ci)):
+                wgt[c, c, ctr[0], ctr[1]] += a
+        out[k] = torch.from_numpy(wgt.astype(np.float32))
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # inference helpers
 # ----------------------------------------------------------------------------------------------
@@ -447,18 +518,23 @@ def test_mode(model, L, mode=0, refield=32, min_size=256, sf=1, modulo=1):
     raise NotImplementedError('test_mode %d is not reached by the PnP solvers' % mode)
 
 
-def forward_flops(den, H, W, device):
+def forward_flops(den, H, W, device, detail=False):
     """Floating-point operations of ONE denoiser call on one H x W slice: 2 x the multiply-accumulates of every
     Conv2d / ConvTranspose2d the call really executes (counted by forward hooks on a one-slice probe, so the quadrant split of
-    DRUNet above 256 x 256 and the 1/4-resolution FFDNet body are what they are, not what a formula assumes)."""
-    macs = [0]
+    DRUNet above 256 x 256 and the 1/4-resolution FFDNet body are what they are, not what a formula assumes).
+    detail=True -> (total, part): `part` = the flops of the C -> C conv3x3 layers and <= 4-channel last layers that backend
+    'hip_f16x3' runs as THREE half-precision matrix products per float32 product (bench_pnp.py prices those at 3 x)."""
+    macs = [0, 0]
 
     def hook(m, inp, out):
         kh, kw = m.kernel_size
         if isinstance(m, torch.nn.ConvTranspose2d):
-            macs[0] += inp[0].numel() * (m.out_channels // m.groups) * kh * kw
+            n = inp[0].numel() * (m.out_channels // m.groups) * kh * kw
         else:
-            macs[0] += out.numel() * (m.in_channels // m.groups) * kh * kw
+            n = out.numel() * (m.in_channels // m.groups) * kh * kw
+        macs[0] += n
+        if isinstance(m, nn.Conv2d) and (_hip_body_ok(m, 'f16x3') or (_plain3x3(m) and m.in_channels == 64 and m.out_channels <= 4)):
+            macs[1] += n
 
     hs = [m.register_forward_hook(hook) for m in den.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
     swapped = [(m, m.backend) for m in den.model.modules() if getattr(m, 'backend', None) in HIP_BACKENDS]
@@ -473,7 +549,7 @@ def forward_flops(den, H, W, device):
         for m, b in swapped:
             m.backend = b
         den.graph = graph
-    return 2 * macs[0]
+    return (2 * macs[0], 2 * macs[1]) if detail else 2 * macs[0]
 
 
 class Denoiser:
@@ -494,6 +570,7 @@ class Denoiser:
         self.graph = bool(graph)
         self._graphs = {}
         self._sig_static = None
+        self._in_graph = False
         if backend not in ('torch',) + HIP_BACKENDS:
             raise ValueError("backend must be 'torch', 'hip' or 'hip_f16x3'")
         if backend in HIP_BACKENDS and cnn_dtype not in (None, 'fp32'):
@@ -559,7 +636,9 @@ class Denoiser:
         if fam == 'drunet':
             if self.x8:
                 x = augment_img_tensor4(x, i % 8)
-            sig = self.sigmas[i] if self._sig_static is None else self._sig_static     # graph replay: a device scalar refreshed per call
+            # inside _graph_forward (warm-up, capture, replay) the noise level is a device scalar refreshed per call; every other
+            # path -- batches beyond cnn_batch, graph switched off, the flop probe -- reads iteration i's own value
+            sig = self._sig_static if self._in_graph else self.sigmas[i]
             s = sig.float().reshape(1, 1, 1, 1).expand(x.shape[0], 1, x.shape[2], x.shape[3])
             x = test_mode(self.model, torch.cat((x, s), dim=1), mode=2, refield=32, min_size=256, modulo=16)
             if self.x8:
@@ -593,13 +672,17 @@ class Denoiser:
             static_in = x.clone()
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side):                         # warm-up off the capture: weight packing, MIOpen's choices, the allocator
-                for _ in range(2):
-                    self._one(static_in, i)
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_out = self._one(static_in, i)
+            self._in_graph = True
+            try:
+                with torch.cuda.stream(side):                     # warm-up off the capture: weight packing, MIOpen's choices, the allocator
+                    for _ in range(2):
+                        self._one(static_in, i)
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static_out = self._one(static_in, i)
+            finally:
+                self._in_graph = False
             ent = self._graphs[key] = (params, g, static_in, static_out)
         _, g, static_in, static_out = ent
         static_in.copy_(x)

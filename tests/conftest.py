@@ -57,3 +57,16 @@ def rel_l2(a, b):
     dt = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
     a, b = a.astype(dt), b.astype(dt)
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def weights50(name):
+    """The contractive fixture weights behind tests/golden/pnp50_set1_05.npz (oracle/make_golden_pnp.py --fifty): rebuilt bit for bit from
+    the committed seeds and operator-norm gains; IRCNN -> its 25-model bank {str(index): state_dict} (S6:196)."""
+    from pnp_admm_cnc_mri_amd import denoisers as D
+    meta = json.load(open(os.path.join(GOLD, 'pnp_known.json')))
+    seed, gains = meta['known50']['seeds'][name], meta['gains50']
+    net, _, _ = D.build(name)
+    fam = D.family(name)
+    if fam == 'ircnn':
+        return {str(i): D.contractive_state_dict(net, fam, seed + i, gains['%s/%d' % (name, i)]) for i in range(25)}
+    return D.contractive_state_dict(net, fam, seed, gains[name])

@@ -32,7 +32,7 @@ import importlib.util
 _spec = importlib.util.spec_from_file_location('isa_scan', os.path.join(CSRC, 'tools', 'isa_scan.py'))
 isa_scan = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(isa_scan)          # the scanner the Makefile runs on every build (`make check`)
-kernels_of, store_hazards = isa_scan.kernels_of, isa_scan.store_hazards
+kernels_of, store_hazards, dma_order_violations = isa_scan.kernels_of, isa_scan.store_hazards, isa_scan.dma_order_violations
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
 
@@ -142,6 +142,25 @@ def test_f16x3_conv_kernel_resources(asm):
         assert len(mf) == 2 * 9 * 48 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf), mf[:2])
         assert sum(1 for x in mf if x.split(';')[0].rstrip().endswith(', 0')) == 16, n
         assert sum(1 for x in k['body'] if x.startswith('buffer_load_dwordx4') and x.split(';')[0].rstrip().endswith(' lds')) == 4 + 2 * 36, n
+
+
+def test_f16x3_weight_dma_is_older_than_the_loads_counted_behind_it(asm):
+    """The per-tap `s_waitcnt vmcnt(k)` of k_conv3x3_c64_h3 leaves the k loads of an input-prefetch piece in flight and is right only
+    while the tap's four LDS-DMAs were issued BEFORE them (in-order completion); the source pins that with a sched_barrier and this
+    walk over the compiled ISA proves it for every dilation: no group of DMAs is issued before the group before it was published by
+    a barrier with no DMA possibly in flight, and no wave ends with one in flight.  The scanner itself on the shapes it must tell apart:"""
+    D, L = 'buffer_load_dwordx4 v1, s[0:3], s5 offen lds', 'buffer_load_dwordx4 v[2:5], v1, s[0:3], 0 offen'
+    tail = [D] * 4 + ['s_waitcnt vmcnt(0)', 's_barrier', 's_endpgm']
+    assert not dma_order_violations([D] * 4 + [L, L, 's_waitcnt vmcnt(2)', 's_barrier'] + tail)
+    assert not dma_order_violations([L] * 5 + [D, D, L, D, D, 's_waitcnt vmcnt(0)', 's_barrier'] + tail)       # a prologue may interleave: it drains
+    assert dma_order_violations([D, D, D, L, D, L, 's_waitcnt vmcnt(2)', 's_barrier'] + tail)                  # a load moved ahead of a DMA
+    assert dma_order_violations([D] * 4 + [L, L, 's_waitcnt vmcnt(3)', 's_barrier'] + tail)                    # a count one too high
+    assert dma_order_violations([D] * 4 + ['s_waitcnt vmcnt(0)', 's_barrier'] + [D] * 4 + ['s_endpgm'])        # ends with a DMA in flight
+    ks = {n: k for n, k in kernels_of(asm['kernels_conv_f16x3.hip']).items() if 'k_conv3x3_c64_h3' in n}
+    assert len(ks) == 4
+    for n, k in ks.items():
+        assert sum(1 for x in k['body'] if x.startswith('buffer_load') and x.rstrip().endswith(' lds')) >= 76, n
+        assert not dma_order_violations(k['body']), (n, dma_order_violations(k['body'])[:3])
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():

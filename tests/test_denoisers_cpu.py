@@ -210,3 +210,52 @@ def test_f16x3_backend_selection_on_the_cpu():
     assert not D._hip_body_ok(nn.Conv2d(128, 128, 3, 1, 2, dilation=2), 'f16x3')      # wide layers: dilation 1 only
     assert not D._hip_body_ok(nn.Conv2d(96, 96, 3, 1, 1), 'f16x3') and not D._hip_body_ok(nn.Conv2d(128, 64, 3, 1, 1), 'f16x3')
     assert D._hip_body_ok(nn.Conv2d(1024, 1024, 3, 1, 1), 'f16x3') and not D._hip_body_ok(nn.Conv2d(1088, 1088, 3, 1, 1), 'f16x3')
+
+
+# ----------------------------------------------------------------------------------------------
+# The oracle's PnP loops against the UNMODIFIED reference at the presets' own 50 iterations (tests/golden/pnp50_set1_05.npz,
+# contractive fixture weights): both sides run the CNN in CPU PyTorch and the x-update in NumPy, so the oracle -- the checker of
+# every GPU PnP test and of bench_pnp.py's parity key -- must land on the reference's x to float32 round-off, IRCNN's bank switch
+# (S6:289-298 under the np.int shim) included.  The cheap families only: the CPU suite stays within minutes.
+# ----------------------------------------------------------------------------------------------
+def _cpu_denoiser(name, iters, noises):
+    from conftest import weights50
+    from pnp_admm_cnc_mri_amd import utils_pnp
+    net, nlm, sched = D.build(name)
+    w = weights50(name)
+    bank = w if D.family(name) == 'ircnn' else None
+    net.load_state_dict(bank['0'] if bank else w)
+    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1]) if sched else None
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, noises=noises, bank=bank, x8=False)
+
+    def denoise(a, i):
+        den.select_bank(i)
+        with torch.no_grad():
+            return den._one(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None], i)[0, 0].numpy()
+    return den, denoise
+
+
+@pytest.mark.parametrize('name,loop', [('ffdnet_gray', 'cnc'), ('ircnn_gray', 'cnc'), ('ircnn_gray', 'l1')])
+def test_oracle_pnp_loops_at_fifty_iterations_vs_the_unmodified_reference(golden_inputs, name, loop):
+    from conftest import rel_l2
+    from oracle import admm_oracle as O
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    meta = json.load(open(os.path.join(GOLD, 'pnp_known.json')))['known50']
+    gold = np.load(os.path.join(GOLD, 'pnp50_set1_05.npz'))
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    y = O.synthesize(np.float32(golden_inputs['gray'] / 255.), mask, golden_inputs['noises'])
+    den, denoise = _cpu_denoiser(name, 50, golden_inputs['noises'])
+    if loop == 'cnc':
+        o = meta['cnc_d_%s_opts' % name]
+        assert int(o['iter_num']) == 50
+        x = O.pnp_admm_cnc(y, mask, denoise, 50, o['alpha'], o['lambda1'], o['reo'], o['b'])
+        ref, line = gold['cnc_d_' + name], meta['cnc_d_' + name]
+    else:
+        o = meta['l1_d_%s_opts' % name]
+        x = O.pnp_admm_l1(y, mask, denoise, 50, o['reo'])
+        ref, line = gold['l1_d_' + name], meta['l1_d_' + name]
+    assert rel_l2(x, ref) <= 2e-6, rel_l2(x, ref)
+    if name == 'ircnn_gray':
+        assert den.former_idx == 7                                   # the bank was walked down from model 24 to model 7 (sigma 49 -> 15)
+    psnr = O.calculate_psnr(np.round(x.astype(np.float64) * 255.), golden_inputs['gray'])
+    assert ('PSNR: %.4f dB' % psnr if loop == 'cnc' else 'PSNR: %.2f dB' % psnr) in line, (psnr, line)

@@ -5,7 +5,7 @@ float64 result -- the same distance as MIOpen's own fp32 kernels; tolerances: on
 <= 1e-5 (vs the PyTorch / MIOpen forward with the same weights).
 
 The same layer in split-half arithmetic on the f16 matrix cores (csrc/kernels_conv_f16x3.hip, `backend='hip_f16x3'`: every
-float32 operand as two halves, three exact-product v_mfma_f32_32x32x16_f16 per product, float32 accumulation) is held to the
+float32 operand as two halves, three exact-product v_mfma_f32_16x16x32_f16 per product, float32 accumulation) is held to the
 SAME tolerances by the same tests (parameter `math`), plus its own: magnitudes from 1e-6 to 1e4, and a loud failure beyond the
 half range."""
 import ctypes as C
@@ -340,3 +340,26 @@ def test_graph_replay_of_a_forward_equals_the_eager_forward(env, name, backend):
     big = D.Denoiser(name, net, nlm, sigmas=sig, noises=noises, backend=backend, miopen_find=False, graph=True, cnn_batch=2).to('cuda')
     x = torch.rand(5, 1, 256, 256, device='cuda', generator=g)   # more slices than one forward takes: the eager path
     assert _rel(big(x, 0), eager(x, 0)) <= max(tol, 1e-6) and not big._graphs      # (MIOpen: other kernels for other batch sizes)
+
+
+def test_graph_and_eager_calls_of_one_denoiser_each_use_their_own_sigma(env):
+    """A DRUNet `Denoiser(graph=True)` serves calls of at most cnn_batch slices from the graph (noise level = a device scalar refreshed per
+    call) and larger ones eagerly; the eager calls must read iteration i's own sigma, not the scalar the last graph call left behind
+    -- neither after a graph call with another i, nor with the graph switched off afterwards."""
+    torch, D = env['torch'], env['D']
+    g = torch.Generator(device='cuda').manual_seed(5)
+    sig = torch.tensor([40.0 / 255, 25.0 / 255, 8.0 / 255])
+    net, nlm, _ = D.build('drunet_gray')
+    net.load_state_dict(D.seeded_state_dict(net, 5))
+    ref = D.Denoiser('drunet_gray', net.eval(), nlm, sigmas=sig, backend='hip_f16x3', miopen_find=False, cnn_batch=2).to('cuda')
+    den = D.Denoiser('drunet_gray', net, nlm, sigmas=sig, backend='hip_f16x3', miopen_find=False, cnn_batch=2, graph=True).to('cuda')
+    small, large = torch.rand(2, 1, 64, 64, device='cuda', generator=g), torch.rand(5, 1, 64, 64, device='cuda', generator=g)
+    apart = _rel(ref(large, 0), ref(large, 2))
+    assert apart > 1e-3, apart                                      # the noise level matters: a wrong one would show
+    for i_small, i_large in ((0, 2), (2, 1), (1, 0)):
+        assert _rel(den(small, i_small), ref(small, i_small)) <= 1e-5
+        assert den._graphs
+        assert _rel(den(large, i_large), ref(large, i_large)) <= 1e-5, (i_small, i_large)
+    den(small, 2)
+    den.graph = False
+    assert _rel(den(small, 0), ref(small, 0)) <= 1e-5

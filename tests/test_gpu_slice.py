@@ -283,6 +283,38 @@ def test_state_order_is_private_to_the_slice_path(P, golden_inputs, monkeypatch)
         assert rel_l2(xs[b], O.admm_cnc(ys[b].astype(np.complex128), masks[mid[b]], 4)) <= 2e-6
 
 
+def test_a_new_problem_invalidates_the_state_of_the_one_before_it(P, golden_inputs):
+    """include/pnp_mri.h: an upload makes z / w undefined until pnp_init_state or pnp_set_state(z, w).  After a slice-resident loop
+    (state in the kernel's own order) a problem with ANOTHER batch size is uploaded: get_state before any initialisation must not
+    convert under the new batch size (that read the padded arrays beyond the old batch) -- it returns, whatever the values; then
+    both ways of defining the state give the loop of a fresh context."""
+    B0, B1 = 64, 96
+    masks, mid, ys = _problem(golden_inputs, B1)
+    args = (0.45, 0.5, 0.05, 64)
+    with P.Engine(256, 256, Bmax=B1) as fresh:
+        fresh.upload(ys, masks, mid)
+        fresh.init_state()
+        z0, w0 = fresh.get_state()
+        fresh.admm_cnc(3, *args)
+        xr = fresh.x()
+    with P.Engine(256, 256, Bmax=B1) as eng:
+        eng.upload(ys[:B0], masks, mid[:B0])
+        eng.init_state()
+        eng.admm_cnc(2, *args)
+        assert eng.path_name == 'slice'
+        eng.upload(ys, masks, mid)                                  # B0 -> B1 with the state still in the slice order
+        z, w = eng.get_state()                                      # undefined values, defined behaviour
+        assert z.shape == (B1, 256, 256) and w.shape == (B1, 256, 256)
+        eng.init_state()
+        eng.admm_cnc(3, *args)
+        assert np.array_equal(eng.x(), xr)
+        eng.admm_cnc(1, *args)
+        eng.upload(ys[:B0], masks, mid[:B0])                        # and B1 -> B0, state defined through set_state(z, w)
+        eng.set_state(z=z0[:B0], w=w0[:B0])
+        eng.admm_cnc(3, *args)
+        assert np.abs(eng.x() - xr[:B0]).max() <= 2e-6
+
+
 def test_driver_shaped_run_against_the_oracle_on_every_eighth_slice(P):
     """BASELINE.json configs[1] exactly as bench.py runs it for the driver (512 synthetic slices, Q_Random30, S4:176 presets,
     5 + 20 iterations as two calls, slice-resident kernel): 64 of the 512 reconstructions (every eighth slice, both rounds of
