@@ -395,10 +395,11 @@ def seeded_state_dict(module, seed=0, gain=1.0):
 # whole depth, and the map of the network is  a_last x + (a few per cent of seeded features):  a denoiser-like contraction.
 _CONTRACTIVE = {          # role -> (a, eps); 'tail' a is per family below
     'head': (1.0, 0.5), 'body': (1.0, 0.01), 'res0': (0.0, 1.0), 'res2': (0.0, 0.02), 'down': (0.0, 0.5), 'up': (0.0, 0.5), 'tail': (None, 0.01)}
-# x - n(x) families: n ~ 0.15 x.  Direct maps: 0.6 .. 0.7 -- with 0.85 the reference's own PNP_ADMM_L1_D loop (clamps on x, z AND w,
+# x - n(x) families: n ~ 0.15 x (IRCNN) / 0.3 x (DnCNN: with 0.15 the DnCNN-pair preset, alpha 1.2 and lambda 4 (S6:571), amplifies a
+# 1e-6 difference between two float32 convolution implementations ~15 x in 50 iterations; with 0.3, 3 x).  Direct maps: 0.6 .. 0.7 -- with 0.85 the reference's own PNP_ADMM_L1_D loop (clamps on x, z AND w,
 # S3:293-296) grows a pixel-local oscillation in dark regions from iteration ~35 on (profiles/experiments/contractive_sens.py): a property
 # of that loop, not of an implementation, but a fixture must not sit on it
-_CONTRACTIVE_TAIL = {'dncnn': 0.15, 'ircnn': 0.15, 'fdncnn': 0.7, 'ffdnet': 0.6, 'drunet': 0.6}
+_CONTRACTIVE_TAIL = {'dncnn': 0.3, 'ircnn': 0.15, 'fdncnn': 0.7, 'ffdnet': 0.6, 'drunet': 0.6}
 
 
 def contractive_roles(module):

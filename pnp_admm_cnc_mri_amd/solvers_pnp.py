@@ -25,6 +25,7 @@ save_E=, device=, return_info=  as in solvers.py, plus
                             'hip_f16x3': the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores
                             (float32 operands as two halves, exact products, float32 accumulation: float32-level results,
                             2.3 x the float32 kernel's rate; operands must lie within the half range)
+    return_device=False     True: `out` is one torch tensor [B,H,W] on the device instead of the 22-slot list of host arrays (solvers.py)
     cnn_graph=False         True: a denoiser forward of at most cnn_batch slices is captured once per shape into a HIP graph and replayed
                             (the reference's one-slice calls: a forward is a train of short launches; FFDNet 0.50 -> see DESIGN.md 4.8)
 """
@@ -95,16 +96,18 @@ def _device_state(torch, eng, B, H, W, dev):
     return x, z, w
 
 
-def _finish_pnp(torch, job, eng, x, extra):
-    """S6:314-351: img_E = uint8(round(x*255)); metrics on the quantised image."""
+def _finish_pnp(torch, job, eng, x, extra, return_device=False):
+    """S6:314-351: img_E = uint8(round(x*255)); metrics on the quantised image.  return_device: `out` is the device tensor [B,H,W]
+    (solvers.py), no host copy of the reconstructions."""
     xq = torch.round(x * 255.0) / 255.0
-    out, psnr1, info = job.finish(eng, x.reshape(job.B, job.H, job.W).cpu().numpy(), x_dev=xq.contiguous(), extra=extra)
+    xs = x.reshape(job.B, job.H, job.W)
+    out, psnr1, info = job.finish(eng, xs.clone() if return_device else xs.cpu().numpy(), x_dev=xq.contiguous(), extra=extra)
     return out, psnr1, info
 
 
 def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                    testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
-                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False,
+                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False,
                    **PNP_ADMM_CNC_D_opts):
     """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
     import torch
@@ -132,14 +135,14 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
             eng.dual_clamp(x, z_new, w)                                       # S6:305-308
             z, z_new = z_new, z
         torch.cuda.current_stream(dev).synchronize()
-        out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha))
+        out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha), return_device)
     return (out, psnr1, info) if return_info else (out, psnr1)
 
 
 def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
                        testsets='testsets', testset_name='Set1', results='results', save_E=None, device=0,
                        return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
-                       cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='torch', cnn_graph=False, **opts):
+                       cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False, **opts):
     """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
     `faithful_model2_path`: the reference loads model_path1 into BOTH nets (S6:435) although it logs
     path 2; True reproduces that, False loads model_name2's own weights."""
@@ -169,13 +172,13 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
             eng.dual_clamp(x, z_new, w)                                       # S6:522-525
             z, z_new = z_new, z
         torch.cuda.current_stream(dev).synchronize()
-        out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha))
+        out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha), return_device)
     return (out, psnr1, info) if return_info else (out, psnr1)
 
 
 def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                   testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
-                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False,
+                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False,
                   **PNP_ADMM_L1_D_opts):
     """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
     import torch
@@ -198,5 +201,5 @@ def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, t
             den(t, i, out=z)                                                  # S3:290
             eng.dual_clamp(x, z, w)                                           # S3:293-296
         torch.cuda.current_stream(dev).synchronize()
-        out, _, info = _finish_pnp(torch, job, eng, x, '')
+        out, _, info = _finish_pnp(torch, job, eng, x, '', return_device)
     return (out, info) if return_info else out

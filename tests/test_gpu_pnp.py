@@ -215,6 +215,38 @@ def test_config5_shape_512_mixed_masks_drunet(env, tmp_path):
         assert rel_l2(out[b], ref) <= 2e-5, (b, rel_l2(out[b], ref))
 
 
+def test_config5_quadrant_split_on_the_f16x3_backend(env, tmp_path):
+    """config 5's shape on the split-half f16 backend: 9 slices of 512 x 512 (three of each mask of the bank), DRUNet through the batched
+    four-quadrant split of test_mode(mode=2) (36 windows of 288 x 288 in one CNN batch; utils/utils_model.py:91-108), one iteration of the
+    S6:577 preset: every slice within 2e-5 of the PyTorch / MIOpen run, and the oracle loop driven by the f16x3 denoiser itself <= 1e-5."""
+    torch, D = env['torch'], env['D']
+    H = W = 512
+    masks = np.stack([O.synthetic_mask(k, H, W) for k in ('random', 'radial', 'cartesian')])
+    B = 9
+    mid = np.arange(B, dtype=np.int32) % 3
+    ys = np.stack([O.synthetic_problem(b, masks[mid[b]], H, W)[1] for b in range(B)]).astype(np.complex64)
+    name = 'drunet_gray'
+    net, nlm, _ = D.build(name)
+    sd = D.seeded_state_dict(net, 5)
+    opts = dict(alpha=1, iter_num=1, lambda1=0.8, reo=0.8, b=0.45)
+    res = {}
+    for backend in ('torch', 'hip_f16x3'):
+        out, _ = env['S'].PNP_ADMM_CNC_D(name, masks, None, y=ys, mask_id=mid, model=sd, results=str(tmp_path), cnn_backend=backend, **opts)
+        res[backend] = np.stack(out[:B])
+    per_slice = np.linalg.norm((res['hip_f16x3'] - res['torch']).reshape(B, -1), axis=1) / np.linalg.norm(res['torch'].reshape(B, -1), axis=1)
+    assert np.isfinite(res['hip_f16x3']).all() and per_slice.max() <= 2e-5, per_slice
+    from pnp_admm_cnc_mri_amd import utils_pnp
+    net.load_state_dict(sd)
+    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), 1, 49, nlm * 255., 1.0)[1])
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, backend='hip_f16x3').to(torch.device('cuda'))
+
+    def denoise(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return den(t, i)[0, 0].cpu().numpy()
+    ref = O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), masks[mid[B - 1]], denoise, 1, 1, 0.8, 0.8, 0.45)
+    assert rel_l2(res['hip_f16x3'][B - 1], ref) <= 2e-5, rel_l2(res['hip_f16x3'][B - 1], ref)
+
+
 # ----------------------------------------------------------------------------------------------
 # The PnP entry points at the reference's OWN run length: every preset is 50 iterations (S6:569-577, S3:339-347).  Goldens from the
 # unmodified S6 / S3 with the contractive fixture weights (oracle/make_golden_pnp.py --fifty; tests/golden/pnp50_set1_05.npz), on all

@@ -81,8 +81,14 @@ def test_bench_pnp_sub_record():
     rec = bench.pnp_record(steps=1, warmup=1)
     assert set(rec) >= {'config', 'unit', 'torch', 'hip_f16x3', 'speedup', 'note'}, rec
     for b in ('torch', 'hip_f16x3'):
-        assert 'error' not in rec[b] and rec[b]['x_finite'] and rec[b]['value'] > 0, rec[b]
-    assert rec['speedup'] > 1.5 and rec['hip_f16x3']['denoiser_frac_of_fp32_matrix_peak'] > 1.0, rec
+        assert 'error' not in rec[b] and rec[b]['x_finite'] and rec[b]['denoiser_outputs_finite'] and rec[b]['value'] > 0, rec[b]
+        # every child re-proves parity of what it timed: three slices against the oracle's loop with the same denoiser
+        assert rec[b]['parity']['slices'] == [0, 255, 511] and max(rec[b]['parity']['rel_l2_vs_oracle']) <= 1e-5, rec[b]['parity']
+        rf = rec[b]['denoiser_roofline']
+        assert 0 < rf['frac'] <= 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) <= 1e-12, rf      # a PHYSICAL fraction
+    assert rec['torch']['denoiser_roofline']['bound'] == 'mfma_f32' and rec['hip_f16x3']['denoiser_roofline']['bound'] == 'mfma_f16'
+    assert rec['hip_f16x3']['denoiser_roofline']['peak'] == 2.5e6 and rec['hip_f16x3']['denoiser_roofline']['frac_fp32_equivalent'] > 1.0
+    assert rec['speedup'] > 1.5, rec
 
 
 def test_file_names_and_log_formats_follow_each_reference_script(env, golden_inputs, tmp_path):
@@ -340,6 +346,22 @@ def test_config3_full_batch_properties(env, monkeypatch):
     for b in (0, B - 1):
         ref = O.pnp_admm_cnc(ys[b].astype(np.complex128), mask, denoise, 2, 0.9, 1.35, 0.45, 0.3)
         assert rel_l2(full[b], ref) <= 1e-5, (b, rel_l2(full[b], ref))
+    # (d) the split-half f16 backend at the same size: every one of the 512 slices within 2e-5 of the PyTorch / MIOpen run, the
+    # same in-range values, the 64-slice sub-batch bit-equal to its slices inside the batch, and an oracle-loop spot check driven
+    # by the f16x3 denoiser itself
+    fh, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys, model=sd, cnn_backend='hip_f16x3', **opts)
+    fh = np.stack(fh[:B])
+    per_slice = np.linalg.norm((fh - full).reshape(B, -1), axis=1) / np.linalg.norm(full.reshape(B, -1), axis=1)
+    assert np.isfinite(fh).all() and fh.min() >= 0 and fh.max() <= 1 and per_slice.max() <= 2e-5, per_slice.max()
+    subh, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[128:192], model=sd, cnn_backend='hip_f16x3', **opts)
+    assert np.array_equal(np.stack(subh[:64]), fh[128:192])
+    denh = D.Denoiser(name, net, nlm, backend='hip_f16x3').to(torch.device('cuda'))
+
+    def denoise_h(a, i):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+        return denh(t, i)[0, 0].cpu().numpy()
+    ref = O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), mask, denoise_h, 2, 0.9, 1.35, 0.45, 0.3)
+    assert rel_l2(fh[B - 1], ref) <= 1e-5, rel_l2(fh[B - 1], ref)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -404,6 +426,14 @@ def test_config4_shard_full_batch_drunet(env, monkeypatch):
         return den(t, i)[0, 0].cpu().numpy()
     ref = O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), mask, denoise, 1, 1, 0.8, 0.8, 0.45)
     assert rel_l2(full[B - 1], ref) <= 1e-5, rel_l2(full[B - 1], ref)
+    # (c) the split-half f16 backend on the same shard (every convolution of the U-Net on libpnpmri.so): all 512 slices within 2e-5
+    # of the PyTorch / MIOpen run, the last CNN batch alone bit-equal to itself inside the shard
+    fh, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys, model=sd, cnn_backend='hip_f16x3', **opts)
+    fh = np.stack(fh[:B])
+    per_slice = np.linalg.norm((fh - full).reshape(B, -1), axis=1) / np.linalg.norm(full.reshape(B, -1), axis=1)
+    assert np.isfinite(fh).all() and fh.min() >= 0 and fh.max() <= 1 and per_slice.max() <= 2e-5, per_slice.max()
+    subh, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[448:512], model=sd, cnn_backend='hip_f16x3', **opts)
+    assert np.array_equal(np.stack(subh[:64]), fh[448:512])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -521,18 +551,23 @@ def test_bench_pnp_line_and_its_two_rank_launch():
     r = subprocess.run(base, env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
-    assert j['n_gpus'] == 1 and j['gather_ms'] is None and j['x_finite']
+    assert j['n_gpus'] == 1 and j['gather_ms'] is None and j['x_finite'] and j['denoiser_outputs_finite']
+    assert j['config']['weights'] == 'contractive' and j['parity']['iterations'] == 3 and j['parity']['slices'] == [0, 7, 15]
+    assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5, j['parity']
     assert abs(j['denoiser']['flop_per_call_per_slice'] / 1e9 - 15.9) <= 0.4
     assert j['denoiser']['roofline']['bound'] == 'mfma_f32' and 0 < j['denoiser']['roofline']['frac'] < 1
     assert j['fft_prox']['roofline']['bound'] == 'hbm' and j['fft_prox']['algorithmic_bytes'] == 57.0 * 65536 * 16
     assert abs(j['denoiser']['share'] + j['fft_prox']['share'] - 1) < 1e-9
-    r2 = subprocess.run(base + ['--gpus', '2', '--rehearse-gloo'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    # four ranks (the box allows six processes on its card: this one + four ranks), the f16x3 backend, the He-scaled weights of the earlier rounds
+    r2 = subprocess.run(base[:4] + ['--batch', '8', '--steps', '2', '--warmup', '1', '--gpus', '4', '--rehearse-gloo', '--cnn-backend', 'hip_f16x3',
+                                    '--weights', 'he'], env=env_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r2.returncode == 0, r2.stderr.decode()[-3000:]
     lines = [l for l in r2.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1
     j2 = json.loads(lines[0])
-    assert j2['n_gpus'] == 2 and j2['gather_ms'] is not None and j2['scaling'] == 'weak' and j2['x_finite']
-    assert len(j2['per_rank']['ms_per_step']) == 2 and abs(max(j2['per_rank']['ms_per_step']) - j2['ms_per_step']) <= 1e-9
+    assert j2['n_gpus'] == 4 and j2['gather_ms'] is not None and j2['scaling'] == 'weak' and j2['x_finite'] and j2['parity'] is None
+    assert len(j2['per_rank']['ms_per_step']) == 4 and abs(max(j2['per_rank']['ms_per_step']) - j2['ms_per_step']) <= 1e-9
+    assert j2['config']['weights'] == 'he' and j2['denoiser']['roofline']['bound'] == 'mfma_f16' and 0 < j2['denoiser']['roofline']['frac'] <= 1
     # the N > 1 path on the real backend: one rank, 'nccl' (= RCCL) process group, device-tensor gather, all_gather of the clocks
     import socket
     with socket.socket() as so:

@@ -65,3 +65,28 @@ def test_two_ranks_equal_one_process(precision):
     # rank 0 holds slices 0..3 (pairs (0,1),(2,3)), rank 1 slices 4..6; in the single process slice 4
     # is paired with 5 and 6 is alone in both cases, so pairing is identical -> bit-identical
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_return_device_hands_back_the_reconstructions_as_one_device_tensor(tmp_path):
+    """`return_device=True` (what solve_sharded asks of every entry point before the RCCL gather): `out` is ONE [B,H,W] tensor on the
+    device, equal to the host list of the plain call -- ADMM_CNC in both precisions, ADMM_L1, and the PnP entry points."""
+    import torch
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import solvers_pnp as SP, denoisers as D
+    masks, y, mid = _problem()
+    kw = dict(y=y, mask_id=mid, results=str(tmp_path))
+    for fn, opts in ((P.ADMM_CNC, dict(P.PRESETS['ADMM_CNC'], iter_num=4)), (P.ADMM_CNC, dict(P.PRESETS['ADMM_CNC'], iter_num=4, precision='f64')),
+                     (P.ADMM_L1, dict(P.PRESETS['ADMM_L1'], iter_num=4))):
+        host = fn(masks, None, **kw, **opts)
+        dev = fn(masks, None, return_device=True, **kw, **opts)
+        assert torch.is_tensor(dev) and dev.is_cuda and tuple(dev.shape) == (7, 256, 256)
+        assert dev.dtype == (torch.float64 if opts.get('precision') == 'f64' else torch.float32)
+        assert np.array_equal(dev.cpu().numpy().astype(np.float64), np.stack([host[b] for b in range(7)]))
+    sd = D.seeded_state_dict(D.build('ffdnet_gray')[0], 1)
+    o = dict(alpha=0.9, iter_num=2, lambda1=1.35, reo=0.45, b=0.3)
+    host, psnr_h = SP.PNP_ADMM_CNC_D('ffdnet_gray', masks, None, model=sd, **kw, **o)
+    dev, psnr_d = SP.PNP_ADMM_CNC_D('ffdnet_gray', masks, None, model=sd, return_device=True, **kw, **o)
+    assert torch.is_tensor(dev) and dev.is_cuda and np.array_equal(dev.cpu().numpy().astype(np.float64), np.stack([host[b] for b in range(7)]))
+    host = SP.PNP_ADMM_L1_D('ffdnet_gray', masks, None, model=sd, iter_num=2, reo=0.25, **kw)
+    dev = SP.PNP_ADMM_L1_D('ffdnet_gray', masks, None, model=sd, iter_num=2, reo=0.25, return_device=True, **kw)
+    assert torch.is_tensor(dev) and np.array_equal(dev.cpu().numpy().astype(np.float64), np.stack([host[b] for b in range(7)]))

@@ -77,12 +77,15 @@ def test_sharded_equals_single_process(world, B):
     assert got.shape == ref.shape and np.array_equal(got, ref)
 
 
-def _fake_solver(mask, noises, images=None, y=None, mask_id=None, **opts):
-    """same call shape as ADMM_L1: returns the reference-style list (22 slots) of float64 arrays."""
+def _fake_solver(mask, noises, images=None, y=None, mask_id=None, return_device=False, **opts):
+    """same call shape as ADMM_L1: returns the reference-style list (22 slots) of float64 arrays -- or, asked with return_device=True
+    as solve_sharded does, ONE [b,H,W] float32 tensor (here on the CPU: the gloo stand-in of the device tensor)."""
     out = [np.zeros(mask.shape[-2:], np.uint8)] * max(22, len(y))
     for n in range(len(y)):
         k = 0 if mask_id is None else int(mask_id[n])
         out[n] = O.admm_l1(y[n], mask[k], opts.get('iter_num', 2))
+    if return_device:
+        return torch.from_numpy(np.stack([np.asarray(out[n], np.float32) for n in range(len(y))]))
     return out
 
 
@@ -197,3 +200,67 @@ def test_solve_sharded_per_slice_noise_and_subgroup_dst():
     ref = sharding.solve_sharded(_noisy_solver, mask, noises, images=imgs)
     assert got['all'].shape == (5, 64, 64) and np.array_equal(got['all'], ref)
     assert np.array_equal(got['sub'], ref)
+
+
+# ----------------------------------------------------------------------------------------------
+# First contact with 8 GPUs, rehearsed on the CPU: world 8 over gloo with the shard arithmetic of BASELINE.json configs[3] / [4]
+# (4096 / 8 and 2048 / 8 slices per rank at 256^2 / 512^2 -- here the same counts scaled down to a tiny H x W so that 8 processes
+# finish in seconds), per-slice mask ids b % 3, and an uneven remainder case.  Bit-equal to one process.
+# ----------------------------------------------------------------------------------------------
+def _tiny_solver(mask, noises, images=None, y=None, mask_id=None, return_device=False, **opts):
+    """entry-point shape on 8 x 8 slices: one DC step + soft threshold per slice (slice-independent, mask bank + mask_id)"""
+    xs = []
+    for n in range(len(y)):
+        m = mask[int(mask_id[n])]
+        X = np.fft.fft2(np.abs(np.fft.ifft2(y[n])))
+        X[m > 0] = (2.0 * X[m > 0] + y[n][m > 0]) / 3.0
+        x = np.abs(np.real(np.fft.ifft2(X)))
+        xs.append(np.float32(np.sign(x) * np.maximum(np.abs(x) - 0.01, 0)))
+    t = torch.from_numpy(np.stack(xs))
+    return t if return_device else [a.astype(np.float64) for a in xs]
+
+
+def _tiny_problem(B):
+    rng = np.random.default_rng(8)
+    masks = (rng.uniform(size=(3, 8, 8)) < 0.4).astype(np.float64)
+    masks[:, 0, 0] = 1
+    mid = (np.arange(B) % 3).astype(np.int32)                        # config 5: mask_id = b % 3
+    y = (rng.standard_normal((B, 8, 8)) + 1j * rng.standard_normal((B, 8, 8))) * masks[mid]
+    return masks, y, mid
+
+
+def _worker8(rank, world, port, Bs, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        for B in Bs:
+            masks, y, mid = _tiny_problem(B)
+            lo, hi = sharding.shard_range(B, world, rank)
+            x = sharding.solve_sharded(_tiny_solver, masks, None, y=y, mask_id=mid)
+            assert (x is not None) == (rank == 0)
+            if rank == 0:
+                q.put((B, x))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_eight_with_the_shard_counts_of_configs_4_and_5():
+    Bs = (4096, 2048, 2051, 5)             # 512 and 256 slices per rank; 2051: three ranks hold one slice more; 5: three ranks hold none
+    assert sharding.shard_sizes(4096, 8) == [512] * 8 and sharding.shard_sizes(2048, 8) == [256] * 8
+    assert sharding.shard_sizes(2051, 8) == [257] * 3 + [256] * 5 and sharding.shard_sizes(5, 8) == [1] * 5 + [0] * 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, Bs, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in Bs)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for B in Bs:
+        masks, y, mid = _tiny_problem(B)
+        ref = sharding.solve_sharded(_tiny_solver, masks, None, y=y, mask_id=mid)
+        assert got[B].shape == (B, 8, 8) and got[B].dtype == np.float32 and np.array_equal(got[B], ref), B
