@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   9
+#define PNP_ABI_VERSION   10
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -231,6 +231,22 @@ int pnp_conv3x3_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_p
  * f16x3 kernel; as a 16-column matrix product it is bound by reading its input.  Same operand range as above.  New in ABI 9. */
 int pnp_conv3x3_tail_nchw_f16x3(void* hip_stream, const float* x_nhwc_dev, const float* w_oihw_dev, const float* bias_dev,
                                 float* y_nchw_dev, int n, int cout, int H, int W);
+/* The same with a second input ADDED to x while it is staged (the U-Net's last skip sum, models/network_unet.py:134-135: the sum never
+ * goes to memory).  New in ABI 10. */
+int pnp_conv3x3_tail_add_nchw_f16x3(void* hip_stream, const float* x_nhwc_dev, const float* x2_nhwc_dev, const float* w_oihw_dev,
+                                    const float* bias_dev, float* y_nchw_dev, int n, int cout, int H, int W);
+/* DRUNet's scale changes in the f16x3 arithmetic (csrc/kernels_pix2x2_f16x3.hip), bias-free as in models/network_unet.py:95-107 with
+ * models/basicblock.py:415-421, 439-445 -- with them `Denoiser(backend='hip_f16x3')` runs DRUNet without a MIOpen call:
+ *   pnp_conv2x2s2_nhwc_f16x3    torch.nn.Conv2d(C, 2C, 2, 2, 0):           x [n][H][W][C] -> y [n][H/2][W/2][2C]  (H, W even; C = 64 k)
+ *   pnp_convT2x2s2_nhwc_f16x3   torch.nn.ConvTranspose2d(C, C/2, 2, 2, 0): x [n][H][W][C] -> y [n][2H][2W][C/2]   (C = 128 k)
+ * x2_dev: NULL, or a tensor of x's shape that is added to x while it is staged (the skip sums `m_up(x + x_skip)`,
+ * models/network_unet.py:131-133).  w_packed from pnp_conv2x2_pack_f16x3 (transposed = 0: a Conv2d weight [2C][C][2][2], 8 C C floats
+ * of storage; 1: a ConvTranspose2d weight [C][C/2][2][2], 2 C C floats).  Same operand range as the layers above.  New in ABI 10. */
+int pnp_conv2x2s2_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* x2_dev, const float* w_packed_dev, float* y_dev,
+                             int n, int C, int H, int W);
+int pnp_convT2x2s2_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* x2_dev, const float* w_packed_dev, float* y_dev,
+                              int n, int C, int H, int W);
+int pnp_conv2x2_pack_f16x3(void* hip_stream, const float* w_dev, float* w_packed_dev, int C, int transposed);
 /* First and last layer of the plain stacks (models/network_dncnn.py:52-62, models/network_ffdnet.py:50-56), direct convolutions:
  *   head: x [n][cin][H][W] (NCHW, 1 <= cin <= 8), w a torch Conv2d(cin, 64, 3) weight [64][cin][3][3] -> y [n][H][W][64] (NHWC), + bias, ReLU
  *   tail: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight [cout][64][3][3], 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias

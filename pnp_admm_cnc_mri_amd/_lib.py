@@ -70,6 +70,10 @@ SIGNATURES = {
     'pnp_conv3x3_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_pack_f16x3': (C.c_int, [_vp, _vp, _vp, C.c_int]),
     'pnp_conv3x3_tail_nchw_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv3x3_tail_add_nchw_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv2x2s2_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_convT2x2s2_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv2x2_pack_f16x3': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     'pnp_conv3x3_head_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_tail_nchw': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_relayout_c64': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -80,7 +84,7 @@ SIGNATURES = {
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 

@@ -949,7 +949,40 @@ int pnp_conv3x3_tail_nchw(void* stream, const float* x, const float* w, const fl
 int pnp_conv3x3_tail_nchw_f16x3(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int cout, int H, int W) {
     if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_tail_nchw_f16x3: null pointer");
     if (n < 1 || H < 1 || W < 1 || cout < 1 || cout > 4) return fail(PNP_E_ARG, "pnp_conv3x3_tail_nchw_f16x3: n, H, W >= 1 and 1 <= cout <= 4 required");
-    HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, w, bias, y, n, cout, H, W));
+    HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, nullptr, w, bias, y, n, cout, H, W));
+    return PNP_OK;
+}
+int pnp_conv3x3_tail_add_nchw_f16x3(void* stream, const float* x, const float* x2, const float* w, const float* bias, float* y, int n, int cout,
+                                    int H, int W) {
+    if (!x || !x2 || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_tail_add_nchw_f16x3: null pointer");
+    if (n < 1 || H < 1 || W < 1 || cout < 1 || cout > 4) return fail(PNP_E_ARG, "pnp_conv3x3_tail_add_nchw_f16x3: n, H, W >= 1 and 1 <= cout <= 4 required");
+    HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, x2, w, bias, y, n, cout, H, W));
+    return PNP_OK;
+}
+static int pix2_args(const char* who, const float* x, const float* w, const float* y, int n, int C, int H, int W, int up) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "%s: null pointer", who);
+    if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "%s: n, H, W must be >= 1", who);
+    if (C < 64 || C > 1024 || C % (up ? 128 : 64)) return fail(PNP_E_ARG, "%s: C must be a multiple of %d in 64..1024 (got %d)", who, up ? 128 : 64, C);
+    if (!up && ((H | W) & 1)) return fail(PNP_E_ARG, "%s: H and W must be even (got %d x %d)", who, H, W);
+    const long long in_b = (long long)H * W * C * 4, out_b = up ? in_b * 2 : in_b / 2;
+    if (in_b > 0x7fffffffLL || out_b > 0x7fffffffLL) return fail(PNP_E_ARG, "%s: an image of %d x %d x %d floats (or its result) exceeds 2 GiB", who, H, W, C);
+    if (x == y) return fail(PNP_E_ARG, "%s: y must not alias x", who);
+    return PNP_OK;
+}
+int pnp_conv2x2s2_nhwc_f16x3(void* stream, const float* x, const float* x2, const float* w, float* y, int n, int C, int H, int W) {
+    if (int rc = pix2_args("pnp_conv2x2s2_nhwc_f16x3", x, w, y, n, C, H, W, 0)) return rc;
+    HIPCHK(launch_pix2x2_f16x3((hipStream_t)stream, x, x2, w, y, n, C, H, W, 0));
+    return PNP_OK;
+}
+int pnp_convT2x2s2_nhwc_f16x3(void* stream, const float* x, const float* x2, const float* w, float* y, int n, int C, int H, int W) {
+    if (int rc = pix2_args("pnp_convT2x2s2_nhwc_f16x3", x, w, y, n, C, H, W, 1)) return rc;
+    HIPCHK(launch_pix2x2_f16x3((hipStream_t)stream, x, x2, w, y, n, C, H, W, 1));
+    return PNP_OK;
+}
+int pnp_conv2x2_pack_f16x3(void* stream, const float* w, float* w_packed, int C, int transposed) {
+    if (!w || !w_packed || w == w_packed) return fail(PNP_E_ARG, "pnp_conv2x2_pack_f16x3: null or aliased pointers");
+    if (C < 64 || C > 1024 || C % (transposed ? 128 : 64)) return fail(PNP_E_ARG, "pnp_conv2x2_pack_f16x3: C must be a multiple of %d in 64..1024 (got %d)", transposed ? 128 : 64, C);
+    HIPCHK(launch_pix2_pack_w_f16x3((hipStream_t)stream, w, w_packed, C, transposed != 0));
     return PNP_OK;
 }
 int pnp_relayout_c64(void* stream, const float* in, float* out, int n, int H, int W, int to_nhwc) {

@@ -1,0 +1,31 @@
+// Shared by the split-half ("f16x3") matrix-core kernels: kernels_conv_f16x3.hip (conv3x3 C -> C) and kernels_pix2x2_f16x3.hip
+// (DRUNet's 2 x 2 stride-2 and transposed convolutions).  DESIGN.md 4.8.
+#pragma once
+#include "conv_common.h"
+
+namespace pnp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr float H3_SCALE = 2048.f, H3_RSCALE = 1.f / 2048.f;
+constexpr int H3_STR = 68;                       // floats between the staging rows of the epilogue
+constexpr int H3_TAP16 = 1024;                   // 16-byte units of one 64 x 64 block of weights: [K step 2][N tile 4][hi, lo][lane 64]
+
+// x = hi + lo / 2048,  hi = half(x),  lo = half((x - hi) * 2048)
+__device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        // two values at a time: ONE packed conversion for the hi halves; (x - h) * 2048 as fma(h, -2048, x * 2048) on the half as it is
+        // (v_fma_mixlo / mixhi_f16) -- both forms are exact: the residual has at most 13 significant bits
+        const f32x2 x = {v[2 * k], v[2 * k + 1]};
+        const h2 h = __builtin_convertvector(x, h2);
+        hi[2 * k] = h[0]; hi[2 * k + 1] = h[1];
+        lo[2 * k] = (_Float16)__builtin_fmaf((float)h[0], -H3_SCALE, x[0] * H3_SCALE);
+        lo[2 * k + 1] = (_Float16)__builtin_fmaf((float)h[1], -H3_SCALE, x[1] * H3_SCALE);
+    }
+}
+
+}  // namespace pnp

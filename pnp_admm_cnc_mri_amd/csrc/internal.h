@@ -81,8 +81,12 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag,
 hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw /*[C][C][3][3]*/, float* wfrag /*9 C C floats*/, int C);
 hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
                                 float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */);
-hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
-                                     int n, int cout, int H, int W);
+hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc /* null or added to x */, const float* w_oihw,
+                                     const float* bias, float* y_nchw, int n, int cout, int H, int W);
+// DRUNet's 2 x 2 stride-2 convolution (C -> 2C, up = 0) and 2 x 2 transposed convolution (C -> C/2, up = 1) in the same arithmetic
+// (kernels_pix2x2_f16x3.hip); x2: null or a tensor of x's shape added to it
+hipError_t launch_pix2_pack_w_f16x3(hipStream_t s, const float* w, float* wfrag /* 8 C C floats (down), 2 C C (up) */, int C, int up);
+hipError_t launch_pix2x2_f16x3(hipStream_t s, const float* x, const float* x2, const float* wfrag, float* y, int n, int C, int H, int W, int up);
 hipError_t launch_relayout64(hipStream_t s, const float* in, float* out, int n, int HW, bool to_nhwc);
 hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
                                int n, int cin, int H, int W, int relu);

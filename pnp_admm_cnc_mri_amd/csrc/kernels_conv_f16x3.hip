@@ -30,16 +30,12 @@
 //                 requested at once would be waited for at the next weight wait), issued unconditionally so that hipcc counts them
 //   first chunk   its own instance of the code: the accumulators start from a constant-zero C operand, not from 64 register moves
 #include "conv_common.h"
+#include "f16x3_common.h"
 #include <type_traits>
 
 namespace pnp {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-constexpr float H3_SCALE = 2048.f, H3_RSCALE = 1.f / 2048.f;
-constexpr int H3_STR = 68;                       // floats between the staging rows of the epilogue
-constexpr int H3_TAP16 = 1024;                   // 16-byte units of one tap's weights: [K step 2][N tile 4][hi, lo][lane 64]
+// (h8 / h4, H3_SCALE, H3_STR, H3_TAP16, split4: f16x3_common.h, shared with kernels_pix2x2_f16x3.hip)
 template <int DIL> struct GeoH {
     static constexpr int LDS = Geo<DIL>::XIN * 4 + 2 * H3_TAP16 * 16;
     static constexpr int WPS = (CV_MT == 1 && LDS <= 80 * 1024) ? 2 : 1;        // 81 728 bytes at dilation 1: two workgroups fill the 160 KiB
@@ -53,21 +49,6 @@ __device__ unsigned long long g_h3prof[1024 * 8];
 #else
 #define H3_STAMP(k)
 #endif
-
-__device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        // two values at a time: ONE packed conversion for the hi halves; (x - h) * 2048 as fma(h, -2048, x * 2048) on the half as it is
-        // (v_fma_mixlo / mixhi_f16) -- both forms are exact: the residual has at most 13 significant bits
-        const f32x2 x = {v[2 * k], v[2 * k + 1]};
-        const h2 h = __builtin_convertvector(x, h2);
-        hi[2 * k] = h[0]; hi[2 * k + 1] = h[1];
-        lo[2 * k] = (_Float16)__builtin_fmaf((float)h[0], -H3_SCALE, x[0] * H3_SCALE);
-        lo[2 * k + 1] = (_Float16)__builtin_fmaf((float)h[1], -H3_SCALE, x[1] * H3_SCALE);
-    }
-}
 
 // Input staging with ONE register per 16-byte chunk (the float32 kernel's Staging<> keeps three; this kernel is at the 256-register
 // line of two workgroups per compute unit): chunk u of thread tid is tile pixel p = stage_pixel(tid) + 16 u = (row r, column c), channels
@@ -366,7 +347,7 @@ __global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Fl
 // 8 x 16 tile, 58 KiB of LDS (the split input tile + the split weights of COUT channels): two workgroups per compute unit.
 // ------------------------------------------------------------------------------------------
 struct TailH3Args {
-    const float* x; const float* w; const float* bias; float* y;
+    const float* x; const float* x2; const float* w; const float* bias; float* y;      // x2: null, or a tensor of x's shape added to it (the U-Net's last skip sum)
     int n, cout, H, W, tiles_x, tiles_y;
 };
 __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t) {
@@ -383,6 +364,13 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
     staging_init_p<1>(a, tid, st, CV_C * 4);
     f32x4 xpre[Geo<1>::XU];
     fetch_input_p<1>(a, q, st, xpre, tid, CV_C * 4, 0);
+    if (t.x2) {                                                   // uniform: x + x2, the sum never goes to memory (models/network_unet.py:134)
+        a.x = t.x2;
+        f32x4 x2pre[Geo<1>::XU];
+        fetch_input_p<1>(a, q, st, x2pre, tid, CV_C * 4, 0);
+#pragma unroll
+        for (int u = 0; u < Geo<1>::XU; ++u) xpre[u] += x2pre[u];
+    }
     // weights: w_oihw [cout][64][3][3] -> split halves in the B operand's order (columns >= cout are zeros the lanes supply themselves)
     for (int e = tid; e < 9 * 2 * 4 * 4 * 8; e += CV_THREADS) {
         const int j = e & 7, n = (e >> 3) & 3, kq = (e >> 5) & 3, s2 = (e >> 7) & 1, tap = e >> 8;
@@ -437,11 +425,11 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
     }
 }
 
-hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
                                      int n, int cout, int H, int W) {
     if (cout < 1 || cout > 4 || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     TailH3Args t;
-    t.x = x_nhwc; t.w = w_oihw; t.bias = bias; t.y = y_nchw; t.n = n; t.cout = cout; t.H = H; t.W = W;
+    t.x = x_nhwc; t.x2 = x2_nhwc; t.w = w_oihw; t.bias = bias; t.y = y_nchw; t.n = n; t.cout = cout; t.H = H; t.W = W;
     t.tiles_x = (W + CV_TX - 1) / CV_TX; t.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long tiles = (long long)n * t.tiles_x * t.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -90,6 +90,24 @@ def _hip_weights(seq, k, conv, L, stream, math='f32'):
     return hit[1]
 
 
+def _hip_weights2x2(owner, conv, L, stream, transposed):
+    """a 2 x 2 stride-2 (transposed) convolution's weight in the fragment order of csrc/kernels_pix2x2_f16x3.hip, cached like _hip_weights"""
+    import ctypes as C
+    from . import _lib
+    cache = owner.__dict__.setdefault('_pnp_hip_w2', {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        src = w.detach().contiguous(memory_format=torch.contiguous_format)
+        if not bool(torch.isfinite(src).all()) or float(src.abs().max()) > 65504.:
+            raise ValueError("backend='hip_f16x3': a convolution weight lies outside the half range (|w| <= 65504)")
+        packed = torch.empty(src.numel(), dtype=torch.float32, device=w.device)
+        _lib.check(L.pnp_conv2x2_pack_f16x3(stream, C.c_void_p(src.data_ptr()), C.c_void_p(packed.data_ptr()), conv.in_channels, 1 if transposed else 0))
+        cache[id(conv)] = hit = (key, packed, src)
+    return hit[1]
+
+
 def _hip_oihw(seq, k, conv):
     """conv.weight as an [out][in][3][3]-contiguous tensor (the parameter may be in channels_last format), cached like the packed
     weights and rebuilt when the parameter changes."""
@@ -255,29 +273,36 @@ class _ResBlock(nn.Module):
         self.res = nn.Sequential(nn.Conv2d(nc, nc, 3, 1, 1, bias=False), nn.ReLU(inplace=True),
                                  nn.Conv2d(nc, nc, 3, 1, 1, bias=False))
 
+    def hip_ok(self):
+        return (self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0], _hip_math(self.backend))
+                and _hip_body_ok(self.res[2], _hip_math(self.backend)))
+
+    def forward_nhwc(self, xn):
+        """the block on a contiguous [n][H][W][C] tensor, on libpnpmri.so (hip_ok() must hold)"""
+        import ctypes as C
+        from . import _lib
+        if not (xn.is_cuda and xn.dtype == torch.float32):
+            raise RuntimeError("Denoiser(backend='hip') needs float32 CUDA tensors")
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(xn.device).cuda_stream)
+        math = _hip_math(self.backend)
+        h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream, math), self.res[0].bias, None, True, 1, math)
+        return _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream, math), self.res[2].bias, xn, False, 1, math)
+
     def forward(self, x):
-        if (self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0], _hip_math(self.backend))
-                and _hip_body_ok(self.res[2], _hip_math(self.backend))):
-            import ctypes as C
-            from . import _lib
-            if not (x.is_cuda and x.dtype == torch.float32):
-                raise RuntimeError("Denoiser(backend='hip') needs float32 CUDA tensors")
-            L = _lib.lib()
-            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        if self.hip_ok():
             xn = x.permute(0, 2, 3, 1)
             if not xn.is_contiguous():
                 xn = xn.contiguous()                           # NCHW-contiguous input: one copy; channels_last tensors pass as they are
-            math = _hip_math(self.backend)
-            h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream, math), self.res[0].bias, None, True, 1, math)
-            y = _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream, math), self.res[2].bias, xn, False, 1, math)
-            return y.permute(0, 3, 1, 2)                       # a channels_last NCHW view
+            return self.forward_nhwc(xn).permute(0, 3, 1, 2)   # a channels_last NCHW view
         return x + self.res(x)
 
 
 class UNetRes(nn.Module):
     """DRUNet: 4 scales, 4 residual blocks each, stride-2 conv down, 2x2 transposed conv up, no bias.  With a HIP backend the
-    first (2 -> 64) and last (64 -> 1) convolution run on libpnpmri.so's direct kernels as well; the 2 x 2 strided / transposed
-    convolutions between the scales stay with PyTorch."""
+    first (2 -> 64) and last (64 -> 1) convolution run on libpnpmri.so's direct kernels as well; under 'hip_f16x3' so do the 2 x 2
+    strided / transposed convolutions between the scales (csrc/kernels_pix2x2_f16x3.hip) and the skip sums: no MIOpen call is left
+    (hip_covers); under 'hip' (float32 matrix cores: 64-channel blocks only) the other layers stay with PyTorch."""
     backend = 'torch'
 
     def __init__(self, in_nc=2, out_nc=1, nc=(64, 128, 256, 512), nb=4):
@@ -298,7 +323,78 @@ class UNetRes(nn.Module):
                 and self.m_head.in_channels <= 8 and self.m_head.out_channels == 64 and _plain3x3(self.m_tail)
                 and self.m_tail.in_channels == 64 and self.m_tail.out_channels <= 4)
 
+    def hip_covers(self, H=None, W=None):
+        """True when EVERY convolution of the U-Net runs on libpnpmri.so under backend 'hip_f16x3': first / last layer, all residual
+        blocks, the three 2 x 2 stride-2 convolutions and the three 2 x 2 transposed ones (csrc/kernels_pix2x2_f16x3.hip) -- such a
+        forward makes no MIOpen call at all.  H, W (if given) must survive three halvings."""
+        if self.backend != 'hip_f16x3' or (H is not None and (H % 8 or W % 8)):
+            return False
+        if not (_plain3x3(self.m_head) and self.m_head.in_channels <= 8 and self.m_head.out_channels == 64 and self.m_head.bias is None
+                and _plain3x3(self.m_tail) and self.m_tail.in_channels == 64 and self.m_tail.out_channels <= 4):
+            return False
+        for seq in (self.m_down1, self.m_down2, self.m_down3):
+            d = seq[-1]
+            if not (isinstance(d, nn.Conv2d) and d.kernel_size == (2, 2) and d.stride == (2, 2) and d.padding == (0, 0) and d.bias is None
+                    and d.groups == 1 and d.dilation == (1, 1) and d.out_channels == 2 * d.in_channels and d.in_channels % 64 == 0 and d.in_channels <= 1024
+                    and all(isinstance(m, _ResBlock) and m.hip_ok() for m in seq[:-1])):
+                return False
+        for seq in (self.m_up3, self.m_up2, self.m_up1):
+            u = seq[0]
+            if not (isinstance(u, nn.ConvTranspose2d) and u.kernel_size == (2, 2) and u.stride == (2, 2) and u.padding == (0, 0) and u.bias is None
+                    and u.output_padding == (0, 0) and u.groups == 1 and u.dilation == (1, 1) and 2 * u.out_channels == u.in_channels
+                    and u.in_channels % 128 == 0 and u.in_channels <= 1024 and all(isinstance(m, _ResBlock) and m.hip_ok() for m in seq[1:])):
+                return False
+        return all(isinstance(m, _ResBlock) and m.hip_ok() for m in self.m_body)
+
+    def _forward_f16x3(self, x0):
+        """models/network_unet.py:123-136 with every tensor NHWC and every layer on libpnpmri.so; the four skip sums are formed inside the
+        kernel that consumes them (transposed convolution / last layer) and never go to memory."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(x0.device).cuda_stream)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        xc = x0.contiguous()
+        n, _, H, W = xc.shape
+        x1 = torch.empty((n, H, W, 64), dtype=torch.float32, device=x0.device)
+        _lib.check(L.pnp_conv3x3_head_nhwc(stream, ptr(xc), ptr(_hip_oihw(self, 'head', self.m_head)), None, ptr(x1), n, self.m_head.in_channels, H, W, 0))
+
+        def scale(conv, t, t2, up):
+            c = conv.in_channels
+            nn_, h, w, _ = t.shape
+            out = torch.empty((nn_, 2 * h, 2 * w, c // 2) if up else (nn_, h // 2, w // 2, 2 * c), dtype=torch.float32, device=t.device)
+            wp = _hip_weights2x2(self, conv, L, stream, up)
+            _lib.check((L.pnp_convT2x2s2_nhwc_f16x3 if up else L.pnp_conv2x2s2_nhwc_f16x3)(stream, ptr(t), ptr(t2), ptr(wp), ptr(out), nn_, c, h, w))
+            return out
+
+        def down(seq, t):
+            for m in seq[:-1]:
+                t = m.forward_nhwc(t)
+            return scale(seq[-1], t, None, False)
+
+        def up(seq, t, skip):
+            t = scale(seq[0], t, skip, True)                   # m_up(x + x_skip): the sum is formed while the operand is staged
+            for m in seq[1:]:
+                t = m.forward_nhwc(t)
+            return t
+
+        x2 = down(self.m_down1, x1)
+        x3 = down(self.m_down2, x2)
+        x4 = down(self.m_down3, x3)
+        x = x4
+        for m in self.m_body:
+            x = m.forward_nhwc(x)
+        x = up(self.m_up3, x, x4)
+        x = up(self.m_up2, x, x3)
+        x = up(self.m_up1, x, x2)
+        out = torch.empty((n, self.m_tail.out_channels, H, W), dtype=torch.float32, device=x0.device)
+        _lib.check(L.pnp_conv3x3_tail_add_nchw_f16x3(stream, ptr(x), ptr(x1), ptr(_hip_oihw(self, 'tail', self.m_tail)), ptr(self.m_tail.bias), ptr(out),
+                                                     n, self.m_tail.out_channels, H, W))
+        return out
+
     def forward(self, x0):
+        if x0.is_cuda and x0.dtype == torch.float32 and self.hip_covers(x0.shape[-2], x0.shape[-1]):
+            return self._forward_f16x3(x0)
         hip = self._hip_ends(x0)
         if hip:
             import ctypes as C
@@ -701,6 +797,8 @@ class Denoiser:
         find = (min(B, self.cnn_batch) >= 16 and x.is_cuda) if self.miopen_find == 'auto' else bool(self.miopen_find)
         if self.backend in HIP_BACKENDS and isinstance(self.model, _PlainStack) and hip_covers_stack(self.model.model):
             find = False                      # no MIOpen call in this forward: the process-global flag is left alone
+        if isinstance(self.model, UNetRes) and self.model.hip_covers():
+            find = False                      # DRUNet under 'hip_f16x3': every layer on libpnpmri.so (sizes that are no multiple of 8 fall back inside forward)
         cd = torch.backends.cudnn
         before = cd.benchmark
         cd.benchmark = bool(find or before)

@@ -25,7 +25,7 @@ from conftest import ROOT
 CSRC = os.path.join(ROOT, 'pnp_admm_cnc_mri_amd', 'csrc')
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'kernels_conv.hip', 'kernels_conv_f16x3.hip',
-           'api.hip']
+           'kernels_pix2x2_f16x3.hip', 'api.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off']     # = csrc/Makefile CXXFLAGS
 
 import importlib.util
@@ -39,7 +39,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not ins
 
 def _compile(args):
     src, out = args
-    extra = ['-fno-slp-vectorize'] if src == 'kernels_conv_f16x3.hip' else []          # = the Makefile's per-file flag
+    extra = ['-fno-slp-vectorize'] if src in ('kernels_conv_f16x3.hip', 'kernels_pix2x2_f16x3.hip') else []          # = the Makefile's per-file flag
     r = subprocess.run([HIPCC] + FLAGS + extra + ['--cuda-device-only', '-S', os.path.join(CSRC, src), '-o', out],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=CSRC)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -160,6 +160,22 @@ def test_f16x3_weight_dma_is_older_than_the_loads_counted_behind_it(asm):
     assert len(ks) == 4
     for n, k in ks.items():
         assert sum(1 for x in k['body'] if x.startswith('buffer_load') and x.rstrip().endswith(' lds')) >= 76, n
+        assert not dma_order_violations(k['body']), (n, dma_order_violations(k['body'])[:3])
+
+
+def test_pix2x2_kernel_resources(asm):
+    """k_pix2x2_h3 (DRUNet's 2 x 2 strided / transposed convolutions, csrc/kernels_pix2x2_f16x3.hip): four instances (down / up, with / without
+    the added second input), two workgroups per compute unit (<= 80 KiB of LDS, <= 256 registers, no scratch -- the variant with a
+    second input sits close to the line), 48 half-precision matrix instructions per chunk in two unrolled chunks, the weights by LDS-DMA
+    in an order the counted waits can rely on."""
+    ks = {n: k for n, k in kernels_of(asm['kernels_pix2x2_f16x3.hip']).items() if 'k_pix2x2_h3' in n}
+    assert len(ks) == 4, sorted(ks)
+    for n, k in ks.items():
+        i = k['info']
+        assert i['ScratchSize'] == 0 and i['NumVgprs'] + i['NumAgprs'] <= 256 and i['LDSByteSize'] <= 80 * 1024, (n, i)
+        mf = [x for x in k['body'] if x.startswith('v_mfma')]
+        assert len(mf) == 96 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf))
+        assert sum(1 for x in k['body'] if x.startswith('buffer_load') and x.rstrip().endswith(' lds')) == 12, n
         assert not dma_order_violations(k['body']), (n, dma_order_violations(k['body'])[:3])
 
 

@@ -9,6 +9,7 @@ float32 operand as two halves, three exact-product v_mfma_f32_16x16x32_f16 per p
 SAME tolerances by the same tests (parameter `math`), plus its own: magnitudes from 1e-6 to 1e4, and a loud failure beyond the
 half range."""
 import ctypes as C
+C_ = C
 
 import numpy as np
 import pytest
@@ -218,27 +219,78 @@ def test_head_and_tail_layers_against_pytorch(env, n, H, W):
         lib.check(L.pnp_conv3x3_tail_nchw_f16x3(s, p(xn), p(xn), None, p(xn), n, 5, H, W))
 
 
-@pytest.mark.parametrize('backend', ['hip', 'hip_f16x3'])
-def test_hip_backend_of_a_plain_stack_makes_no_miopen_call(env, backend):
-    """FFDNet with backend='hip': head, 13 body layers and tail all run on libpnpmri.so -- torch.nn.functional.conv2d is never
-    reached (checked by making it raise for the duration of the call)."""
+@pytest.mark.parametrize('name,backend', [('ffdnet_gray', 'hip'), ('ffdnet_gray', 'hip_f16x3'), ('drunet_gray', 'hip_f16x3')])
+def test_hip_backend_makes_no_miopen_call(env, name, backend):
+    """FFDNet with a HIP backend: head, 13 body layers and tail all run on libpnpmri.so; DRUNet with 'hip_f16x3': first / last layer, the
+    28 residual blocks, the 2 x 2 strided and transposed convolutions and the skip sums -- torch.nn.Conv2d / ConvTranspose2d are never
+    reached (checked by making both raise for the duration of the call), and the process-global cudnn.benchmark flag is left alone."""
     torch, D, F = env['torch'], env['D'], env['F']
-    net, nlm, _ = D.build('ffdnet_gray')
+    net, nlm, sched = D.build(name)
     net.load_state_dict(D.seeded_state_dict(net, 3))
-    den = D.Denoiser('ffdnet_gray', net.eval(), nlm, backend=backend, miopen_find=False).to('cuda')
-    x = torch.rand(2, 1, 64, 64, device='cuda')
-    ref = D.Denoiser('ffdnet_gray', net, nlm, backend='torch', miopen_find=False)(x, 0).clone()
-    net.backend = backend
-    orig = torch.nn.Conv2d.forward
+    sig = torch.tensor([20.0 / 255]) if sched else None
+    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, backend=backend, miopen_find='auto').to('cuda')
+    x = torch.rand(17, 1, 64, 64, device='cuda')                   # >= 16 slices: 'auto' would switch MIOpen's find mode on for a forward that needs it
+    ref = D.Denoiser(name, net, nlm, sigmas=sig, backend='torch', miopen_find=False).to('cuda')(x, 0).clone()
+    for m in [net] + list(net.modules()):
+        if hasattr(m, 'backend'):
+            m.backend = backend
+    orig, orig_t, seen = torch.nn.Conv2d.forward, torch.nn.ConvTranspose2d.forward, []
 
-    def boom(self, inp):
+    def boom(self, inp, *a):
+        seen.append(torch.backends.cudnn.benchmark)
         raise AssertionError('a PyTorch convolution was called')
-    torch.nn.Conv2d.forward = boom
+    torch.nn.Conv2d.forward = torch.nn.ConvTranspose2d.forward = boom
+    before = torch.backends.cudnn.benchmark
     try:
         out = den(x, 0)
     finally:
-        torch.nn.Conv2d.forward = orig
-    assert _rel(out, ref) <= 1e-5
+        torch.nn.Conv2d.forward, torch.nn.ConvTranspose2d.forward = orig, orig_t
+    assert torch.backends.cudnn.benchmark == before and not seen
+    assert _rel(out, ref) <= 1e-5, _rel(out, ref)
+
+
+@pytest.mark.parametrize('up,C,n,H,W', [(0, 64, 3, 40, 56), (0, 128, 2, 24, 24), (0, 256, 2, 16, 32), (0, 64, 1, 2, 2), (0, 192, 1, 6, 34),
+                                       (1, 128, 3, 20, 28), (1, 256, 2, 12, 12), (1, 512, 2, 8, 16), (1, 128, 1, 1, 1), (1, 384, 1, 3, 17),
+                                       (0, 64, 8, 128, 128), (1, 128, 8, 64, 64)])
+@pytest.mark.parametrize('with_x2', [False, True])
+def test_pix2x2_layers_against_pytorch(env, up, C, n, H, W, with_x2):
+    """DRUNet's scale changes on csrc/kernels_pix2x2_f16x3.hip: Conv2d(C, 2C, 2, 2, 0) and ConvTranspose2d(C, C/2, 2, 2, 0), bias-free, NHWC,
+    with and without the second input that is added while the operand is staged -- against the float64 PyTorch operator on the same
+    data, at the tolerance of the 3 x 3 layers (one layer <= 2e-6); tiles that overhang the image, one-tile and one-pixel images."""
+    torch, F, L, lib = env['torch'], env['F'], env['L'], env['lib']
+    g = torch.Generator(device='cuda').manual_seed(100 * C + 10 * H + up)
+    x = torch.randn(n, H, W, C, device='cuda', generator=g)
+    x2 = torch.randn(n, H, W, C, device='cuda', generator=g) if with_x2 else None
+    if up:
+        w = torch.randn(C, C // 2, 2, 2, device='cuda', generator=g) * (1.0 / C) ** 0.5
+        ref = F.conv_transpose2d((x + x2 if with_x2 else x).double().permute(0, 3, 1, 2), w.double(), stride=2).permute(0, 2, 3, 1)
+        y = torch.full((n, 2 * H, 2 * W, C // 2), float('nan'), device='cuda')
+    else:
+        w = torch.randn(2 * C, C, 2, 2, device='cuda', generator=g) * (0.25 / C) ** 0.5
+        ref = F.conv2d((x + x2 if with_x2 else x).double().permute(0, 3, 1, 2), w.double(), stride=2).permute(0, 2, 3, 1)
+        y = torch.full((n, H // 2, W // 2, 2 * C), float('nan'), device='cuda')
+    s = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C_.c_void_p(t.data_ptr())
+    wp = torch.empty(w.numel(), device='cuda')
+    lib.check(L.pnp_conv2x2_pack_f16x3(s, p(w), p(wp), C, up))
+    lib.check((L.pnp_convT2x2s2_nhwc_f16x3 if up else L.pnp_conv2x2s2_nhwc_f16x3)(s, p(x), p(x2), p(wp), p(y), n, C, H, W))
+    assert bool(torch.isfinite(y).all())                            # every output element was written
+    assert _rel(y, ref) <= 2e-6, _rel(y, ref)
+
+
+def test_pix2x2_argument_errors(env):
+    torch, L, lib = env['torch'], env['L'], env['lib']
+    s = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.zeros(1, 6, 6, 128, device='cuda')
+    p = lambda t: None if t is None else C_.c_void_p(t.data_ptr())
+    for fn, args in ((L.pnp_conv2x2s2_nhwc_f16x3, (s, p(x), None, p(x), p(x), 1, 128, 6, 6)),             # y aliases x
+                     (L.pnp_conv2x2s2_nhwc_f16x3, (s, p(x), None, p(x), None, 1, 128, 6, 6)),             # null y
+                     (L.pnp_conv2x2s2_nhwc_f16x3, (s, p(x), None, p(x), p(x[:, :5]), 1, 128, 5, 6)),      # odd H
+                     (L.pnp_conv2x2s2_nhwc_f16x3, (s, p(x), None, p(x), p(x[:, :4]), 1, 100, 6, 6)),      # C no multiple of 64
+                     (L.pnp_convT2x2s2_nhwc_f16x3, (s, p(x), None, p(x), p(x[:, :4]), 1, 64, 6, 6)),      # transposed: C must be a multiple of 128
+                     (L.pnp_conv2x2_pack_f16x3, (s, p(x), p(x), 128, 0))):                                # aliased
+        with pytest.raises(lib.PnpError):
+            lib.check(fn(*args))
 
 
 def test_relayout_round_trip_and_argument_errors(env):
