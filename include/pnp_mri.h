@@ -226,6 +226,18 @@ int pnp_conv3x3_c64_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float*
 int pnp_conv3x3_nhwc_f16x3(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
                            const float* skip_dev, float* y_dev, int n, int C, int H, int W, int relu);
 int pnp_conv3x3_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_packed_dev, int C);
+/* The f16x3 layer with its tensors in the SPLIT ACTIVATION FORMAT, for chains of such layers (a plain stack's body, DRUNet's residual
+ * blocks): a tensor keeps its shape and bytes -- [n][H][W][C], 256 bytes per pixel and block of 64 channels -- but a block holds
+ * [64 hi halves][64 lo halves] of its 64 values, value = hi + lo / 2048 (the float32 result rounded to 2^-22 relative: what the
+ * consuming layer's operands carry anyway).  The PRODUCING layer splits each output once in its epilogue; a consuming layer copies
+ * 16-byte runs of halves into its operand tile instead of splitting every value of every tile again for every block of output
+ * channels.  fmt: a mask saying which of x, skip, y are split (0 = all float32 = pnp_conv3x3_nhwc_f16x3); dilation 1..4 at C = 64, 1
+ * otherwise.  New in ABI 10. */
+#define PNP_FMT_X_SPLIT    1
+#define PNP_FMT_SKIP_SPLIT 2
+#define PNP_FMT_Y_SPLIT    4
+int pnp_conv3x3_nhwc_f16x3_fmt(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
+                               const float* skip_dev, float* y_dev, int n, int C, int H, int W, int relu, int dilation, int fmt);
 /* pnp_conv3x3_tail_nchw (below) in the f16x3 arithmetic: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight (split inside the
  * kernel), 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias.  On the vector units this layer costs as much as a 64 -> 64 layer of the
  * f16x3 kernel; as a 16-column matrix product it is bound by reading its input.  Same operand range as above.  New in ABI 9. */

@@ -68,6 +68,7 @@ SIGNATURES = {
     'pnp_conv3x3_c64_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_c64_pack_f16x3': (C.c_int, [_vp, _vp, _vp]),
     'pnp_conv3x3_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv3x3_nhwc_f16x3_fmt': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_pack_f16x3': (C.c_int, [_vp, _vp, _vp, C.c_int]),
     'pnp_conv3x3_tail_nchw_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_tail_add_nchw_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -923,6 +923,18 @@ int pnp_conv3x3_nhwc_f16x3(void* stream, const float* x, const float* w, const f
     HIPCHK(launch_conv3x3_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, C, H, W, relu, 1));
     return PNP_OK;
 }
+int pnp_conv3x3_nhwc_f16x3_fmt(void* stream, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                               int n, int C, int H, int W, int relu, int dilation, int fmt) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: null pointer");
+    if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: n, H, W must be >= 1");
+    if (C < 64 || C > 1024 || C % 64) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: C must be a multiple of 64 in 64..1024 (got %d)", C);
+    if (dilation < 1 || dilation > 4 || (C != 64 && dilation != 1)) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: dilation 1..4 at C = 64, 1 otherwise (got %d)", dilation);
+    if (fmt & ~7) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: fmt is a mask of PNP_FMT_X_SPLIT | PNP_FMT_SKIP_SPLIT | PNP_FMT_Y_SPLIT (got %d)", fmt);
+    if ((long long)H * W * C * 4 > 0x7fffffffLL) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: an image of %d x %d x %d floats exceeds 2 GiB", H, W, C);
+    if (x == y || skip == y) return fail(PNP_E_ARG, "pnp_conv3x3_nhwc_f16x3_fmt: y must not alias x or skip (tiles read their neighbours' halo)");
+    HIPCHK(launch_conv3x3_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, C, H, W, relu, dilation, fmt));
+    return PNP_OK;
+}
 int pnp_conv3x3_pack_f16x3(void* stream, const float* w_oihw, float* w_packed, int C) {
     if (!w_oihw || !w_packed || w_oihw == w_packed) return fail(PNP_E_ARG, "pnp_conv3x3_pack_f16x3: null or aliased pointers");
     if (C < 64 || C > 1024 || C % 64) return fail(PNP_E_ARG, "pnp_conv3x3_pack_f16x3: C must be a multiple of 64 in 64..1024 (got %d)", C);

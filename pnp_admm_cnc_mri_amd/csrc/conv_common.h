@@ -57,7 +57,9 @@ struct ConvArgs {
     float* y;             // [n][H][W][64]
     int n, H, W, tiles_x, tiles_y, relu;
     int C;                // kernels_conv_f16x3.hip: channels in = out, a multiple of 64 (the float32 kernel is 64 only)
+    int fmt;              // kernels_conv_f16x3.hip: which tensors are in the SPLIT activation format (f16x3_common.h): CV_FMT_X | CV_FMT_SKIP | CV_FMT_Y
 };
+constexpr int CV_FMT_X = 1, CV_FMT_SKIP = 2, CV_FMT_Y = 4;
 
 // where tile `t` of the launch lies
 struct TilePos { int img, y0, x0; };

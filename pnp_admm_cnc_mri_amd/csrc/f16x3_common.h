@@ -28,4 +28,12 @@ __device__ __forceinline__ void split4(const f32x4& v, h4& hi, h4& lo) {
     }
 }
 
+// The SPLIT activation format: what the f16x3 kernels hand to each other between layers instead of float32.  Same shape, same bytes --
+// [n][H][W][C] with 256 bytes per pixel and block of 64 channels -- but a block is [64 hi halves][64 lo halves] of its 64 values
+// (the operand layout of the kernels' LDS tiles): the producing layer splits each output value ONCE in its epilogue, and a consuming
+// layer copies 16-byte runs of halves into its tile instead of splitting every value of every tile (halo included) again for every
+// block of output channels.  A value read back is hi + lo / 2048: the float32 result rounded to 2^-22 relative -- the precision the
+// consumer's operands had anyway.
+__device__ __forceinline__ float unsplit(const _Float16 hi, const _Float16 lo) { return fmaf((float)lo, H3_RSCALE, (float)hi); }
+
 }  // namespace pnp

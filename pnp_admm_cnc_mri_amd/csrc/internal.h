@@ -80,7 +80,8 @@ hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag,
 // the same layer in split-half arithmetic on the f16 matrix cores (kernels_conv_f16x3.hip): own packing, same buffer size
 hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw /*[C][C][3][3]*/, float* wfrag /*9 C C floats*/, int C);
 hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
-                                float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */);
+                                float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */,
+                                int fmt = 0 /* bit 0: x, bit 1: skip, bit 2: y in the split activation format (f16x3_common.h) */);
 hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc /* null or added to x */, const float* w_oihw,
                                      const float* bias, float* y_nchw, int n, int cout, int H, int W);
 // DRUNet's 2 x 2 stride-2 convolution (C -> 2C, up = 0) and 2 x 2 transposed convolution (C -> C/2, up = 1) in the same arithmetic

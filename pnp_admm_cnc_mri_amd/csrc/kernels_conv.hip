@@ -215,7 +215,7 @@ int conv_compute_units() {
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
                               int n, int H, int W, int relu, int dilation) {
     ConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu; a.C = CV_C;
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu; a.C = CV_C; a.fmt = 0;
     a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -101,8 +101,18 @@ __device__ __forceinline__ void fetch_input_p(const ConvArgs& a, const TilePos& 
 
 // registers -> LDS tile, split on the way: chunk u of thread tid = 4 consecutive channels cq of tile pixel stage_pixel(tid) + 16 u --
 // one base address per thread, the chunks are immediate offsets
+// in_split (uniform): the tensor is in the SPLIT activation format (f16x3_common.h) -- the 16 bytes of chunk u are eight halves that go
+// into the tile as they are: one ds_write_b128, no arithmetic
 template <int DIL>
-__device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&v)[Geo<DIL>::XU]) {
+__device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&v)[Geo<DIL>::XU], const bool in_split = false) {
+    if (in_split) {
+        char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + 16 * (tid & 15);
+#pragma unroll
+        for (int u = 0; u < Geo<DIL>::XU; ++u)
+            if (stage_pixel(tid) + 16 * u < Geo<DIL>::HY * Geo<DIL>::HX)
+                *reinterpret_cast<f32x4*>(px + u * (16 * CV_PS * 4)) = v[u];
+        return;
+    }
     char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + 8 * (tid & 15);
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u)
@@ -112,6 +122,77 @@ __device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&
             *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4)) = hi;
             *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4) + 128) = lo;
         }
+}
+
+// The epilogue's second half when the skip input and / or the output are in the SPLIT format (store_rows32 of conv_common.h is the
+// all-float32 one).  The wave's 32 pixels x 64 channels lie in `stage` in pixel order; a lane takes EIGHT consecutive channels
+// (octet co = lane & 7) of pixel slot lane >> 3, four times: staged row m = 8 it + (lane >> 3) = tile row 2 w + (m >> 4), column m & 15.
+// Eight channels are 32 bytes of a float32 pixel (two 16-byte accesses) or 16 bytes of hi halves + 16 bytes of lo halves, 128 bytes
+// apart, of a split one: as many loads and stores per lane as the float32 epilogue issues.  y = relu?(staged + skip); the bias is
+// already in the staged values (added when the accumulators were staged: four registers there instead of eight here).
+template <int STR>
+__device__ __forceinline__ void store_rows32_fmt(const ConvArgs& a, const TilePos& q, const float* stage, int wv, int lane,
+                                                 const int pix, const int coff) {
+    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
+    const __amdgpu_buffer_rsrc_t rk = image_rsrc((a.skip ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, coff);
+    // (opaque copy of the lane number: everything derived from it is computed HERE, per item -- hoisted out of the item loop as the
+    // loop invariants they are, these few values would live through the tap loop, which has no register to spare)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int ps = ln >> 3, co = ln & 7;
+    const bool ksplit = (a.fmt & CV_FMT_SKIP) != 0, ysplit = (a.fmt & CV_FMT_Y) != 0;
+    int pb[4];                                                   // byte offset of the pixel's 64-channel block, or out of range
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = 8 * it + ps, gx = q.x0 + (m & 15);
+        pb[it] = gx < a.W ? ((q.y0 + 2 * wv + (m >> 4)) * a.W + gx) * pix : -256;      // rows below the image: beyond the buffer's range
+    }
+    // all eight skip requests first: one memory round trip
+#pragma unroll
+    for (int hh = 0; hh < 1; ++hh) {
+        u32x4v k0[4], k1[4];
+        if (a.skip) {
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const int it = 4 * hh + e2;
+                k0[e2] = __builtin_amdgcn_raw_buffer_load_b128(rk, pb[it] + (ksplit ? 16 * co : 32 * co), 0, 0);
+                k1[e2] = __builtin_amdgcn_raw_buffer_load_b128(rk, pb[it] + (ksplit ? 16 * co + 128 : 32 * co + 16), 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int it = 4 * hh + e2;
+            const float* sp = stage + (8 * it + ps) * STR + 8 * co;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            if (a.skip) {
+                if (ksplit) {
+                    const h8 kh = __builtin_bit_cast(h8, k0[e2]), kl = __builtin_bit_cast(h8, k1[e2]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] += unsplit(kh[e], kl[e]); v1[e] += unsplit(kh[4 + e], kl[4 + e]); }
+                } else {
+                    v0 += f32x4{__uint_as_float(k0[e2].x), __uint_as_float(k0[e2].y), __uint_as_float(k0[e2].z), __uint_as_float(k0[e2].w)};
+                    v1 += f32x4{__uint_as_float(k1[e2].x), __uint_as_float(k1[e2].y), __uint_as_float(k1[e2].z), __uint_as_float(k1[e2].w)};
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = relu_keep_nan(v0[e]); v1[e] = relu_keep_nan(v1[e]); }
+            }
+            if (ysplit) {
+                h4 h0, l0, h1, l1;
+                split4(v0, h0, l0);
+                split4(v1, h1, l1);
+                const h8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}, lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, hi), ry, pb[it] + 16 * co, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, lo), ry, pb[it] + 16 * co + 128, 0, 0);
+            } else {
+                const u32x4v o0 = {__float_as_uint(v0[0]), __float_as_uint(v0[1]), __float_as_uint(v0[2]), __float_as_uint(v0[3])};
+                const u32x4v o1 = {__float_as_uint(v1[0]), __float_as_uint(v1[1]), __float_as_uint(v1[2]), __float_as_uint(v1[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o0, ry, pb[it] + 32 * co, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, ry, pb[it] + 32 * co + 16, 0, 0);
+            }
+        }
+    }
 }
 
 template <int DIL>
@@ -150,8 +231,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(&wbuf[buf_][wv * 64 + 256 * j]), 16, wvoff, \
                                                  wbase + (t_) * (H3_TAP16 * 16) + j * 4096, 0, 0);
+    const bool in_split = (a.fmt & CV_FMT_X) != 0;               // uniform, the whole launch
     H3_DMA(0, 0)
-    put_input_h3<DIL>(xin, tid, xpre);
+    put_input_h3<DIL>(xin, tid, xpre, in_split);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int par = 0;                                                 // buffer of the current tap
     int t1 = 1 >= period ? 0 : 1;                                // stream position of the next tap's weights
@@ -277,17 +359,24 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 // into the wave's staging rows (pixel order, 68 floats apart: the four lane groups of a write start 16 banks apart)
                 float* stage = xin + wv * (32 * H3_STR);
 #ifndef H3_ABL_NOEPI
+                const bool fmt_epi = (a.fmt & (CV_FMT_SKIP | CV_FMT_Y)) != 0;
+                float bs[4] = {0.f, 0.f, 0.f, 0.f};                    // the split-format epilogue takes the bias here (this lane's four channels)
+                if (fmt_epi && a.bias) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) bs[nt] = a.bias[64 * cb + 16 * nt + i];
+                }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            stage[(16 * mt + 4 * kb + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]);
+                            stage[(16 * mt + 4 * kb + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]) + bs[nt];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                store_rows32<H3_STR>(a, q, stage, wv, lane, 0, pix, 64 * cb, a.bias ? a.bias + 64 * cb : nullptr);
+                if (fmt_epi) store_rows32_fmt<H3_STR>(a, q, stage, wv, lane, pix, 64 * cb);
+                else store_rows32<H3_STR>(a, q, stage, wv, lane, 0, pix, 64 * cb, a.bias ? a.bias + 64 * cb : nullptr);
 #else
                 if (mainv[0][0][0] + corrv[1][3][3] == 123.456f) a.y[tid] = 1.f;
 #endif
@@ -295,7 +384,7 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 if (more) __syncthreads();                           // every wave is done with the staging area
             }
 #ifndef H3_ABL_NOPUT
-            if (more) put_input_h3<DIL>(xin, tid, xpre);         // published by the barrier of the next chunk's first tap
+            if (more) put_input_h3<DIL>(xin, tid, xpre, in_split);     // published by the barrier of the next chunk's first tap
 #else
             if (more && xpre[0][0] + xpre[5][1] + xpre[11][2] == 123.456f) a.y[tid] = 2.f;
 #endif
@@ -358,7 +447,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kb = lane >> 4;
     ConvArgs a;                                                   // the staging helpers' view of the input
-    a.x = t.x; a.H = t.H; a.W = t.W; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
+    a.x = t.x; a.H = t.H; a.W = t.W; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y; a.fmt = 0;
     const TilePos q = tile_pos(a, blockIdx.x);
     StagingP<1> st;
     staging_init_p<1>(a, tid, st, CV_C * 4);
@@ -451,10 +540,10 @@ static hipError_t launch_h3_dil(hipStream_t s, const ConvArgs& a, long long item
 }
 
 hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
-                                int n, int C, int H, int W, int relu, int dilation) {
-    if (C < 64 || C > 1024 || (C & 63) || (C != 64 && dilation != 1)) return hipErrorInvalidValue;
+                                int n, int C, int H, int W, int relu, int dilation, int fmt) {
+    if (C < 64 || C > 1024 || (C & 63) || (C != 64 && dilation != 1) || (fmt & ~(CV_FMT_X | CV_FMT_SKIP | CV_FMT_Y))) return hipErrorInvalidValue;
     ConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu; a.C = C;
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu; a.C = C; a.fmt = fmt;
     a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long items = (long long)n * a.tiles_x * a.tiles_y * (C >> 6);
     if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;

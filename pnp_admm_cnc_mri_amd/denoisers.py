@@ -55,6 +55,41 @@ def _hip_math(backend):
     return 'f16x3' if backend == 'hip_f16x3' else 'f32'
 
 
+# The SPLIT activation format the f16x3 layers hand to each other (include/pnp_mri.h, pnp_conv3x3_nhwc_f16x3_fmt): same shape and bytes
+# as the float32 NHWC tensor, every block of 64 channels stored as [64 hi halves][64 lo halves], value = hi + lo / 2048.
+FMT_X, FMT_SKIP, FMT_Y = 1, 2, 4
+
+
+def split_activations(x_nhwc):
+    """float32 [n][H][W][C] -> the same-shaped float32-typed tensor holding the split format (tests, debugging; the kernels do this
+    in their epilogues)"""
+    n, H, W, Cc = x_nhwc.shape
+    hi = x_nhwc.to(torch.float16)
+    lo = ((x_nhwc - hi.float()) * 2048.0).to(torch.float16)
+    blk = torch.stack((hi.reshape(n, H, W, Cc // 64, 64), lo.reshape(n, H, W, Cc // 64, 64)), dim=4)       # [n][H][W][C/64][2][64] halves
+    return blk.contiguous().view(torch.float32).reshape(n, H, W, Cc)
+
+
+def unsplit_activations(s_nhwc):
+    """the inverse: split format -> float32 values hi + lo / 2048"""
+    n, H, W, Cc = s_nhwc.shape
+    blk = s_nhwc.contiguous().view(torch.float16).reshape(n, H, W, Cc // 64, 2, 64).float()
+    return (blk[..., 0, :] + blk[..., 1, :] / 2048.0).reshape(n, H, W, Cc)
+
+
+def _check_range(t_nhwc, split, where):
+    """PNP_CONV_CHECK_RANGE=1 (bring-up with real KAIR weights): every activation handed to an f16x3 layer must be finite and within the
+    half range -- beyond +-65504 the layer's operands turn into inf / NaN (loudly, but only at the output).  Off by default: it
+    synchronises the stream at every layer."""
+    import os
+    if os.environ.get('PNP_CONV_CHECK_RANGE') != '1':
+        return
+    v = unsplit_activations(t_nhwc) if split else t_nhwc
+    if not bool(torch.isfinite(v).all()) or float(v.abs().max()) > 65504.:
+        raise FloatingPointError("backend='hip_f16x3': an activation entering %s is not finite or lies outside the half range "
+                                 "(|x| <= 65504): max |x| = %r" % (where, float(torch.nan_to_num(v.abs(), nan=float('inf')).max())))
+
+
 def _hip_body_ok(conv, math='f32'):
     """a 64 -> 64 conv3x3, stride 1, dilation d in 1..4 with zero padding d: the layers libpnpmri.so's matrix-core kernels take
     (d = 1: DnCNN / FDnCNN / FFDNet bodies, DRUNet's 64-channel blocks; d = 2..4: IRCNN, models/network_dncnn.py:87-101); the
@@ -142,6 +177,7 @@ def hip_stack_forward(seq, x, math='f32'):
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     mods = list(seq)
     h, nhwc, k = x, None, 0                                    # h: NCHW tensor, or nhwc: [n][H][W][64] between HIP layers
+    nhwc_split = False                                         # f16x3: `nhwc` is in the split activation format (between two body layers)
     while k < len(mods):
         m = mods[k]
         relu = k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU)
@@ -162,10 +198,18 @@ def hip_stack_forward(seq, x, math='f32'):
                     nhwc = torch.empty(hp.shape, dtype=h.dtype, device=h.device)
                     _lib.check(L.pnp_relayout_c64(stream, ptr(h.contiguous()), ptr(nhwc), h.shape[0], h.shape[2], h.shape[3], 1))
             n, H, W, _ = nhwc.shape
-            out = torch.empty_like(nhwc)
-            _lib.check(conv64(stream, ptr(nhwc), ptr(_hip_weights(seq, k, m, L, stream, math)), ptr(m.bias), None, ptr(out),
-                              n, H, W, 1 if relu else 0, m.dilation[0]))
-            nhwc = out
+            if math == 'f16x3':
+                # a body layer followed by another body layer hands its result over in the split activation format
+                kn = k + (2 if relu else 1)
+                out_split = kn < len(mods) and _hip_body_ok(mods[kn], math)
+                nhwc = _hip_conv64(L, stream, nhwc, _hip_weights(seq, k, m, L, stream, math), m.bias, None, relu, m.dilation[0], math,
+                                   (FMT_X if nhwc_split else 0) | (FMT_Y if out_split else 0))
+                nhwc_split = out_split
+            else:
+                out = torch.empty_like(nhwc)
+                _lib.check(conv64(stream, ptr(nhwc), ptr(_hip_weights(seq, k, m, L, stream, math)), ptr(m.bias), None, ptr(out),
+                                  n, H, W, 1 if relu else 0, m.dilation[0]))
+                nhwc = out
             k += 2 if relu else 1
             continue
         if nhwc is not None and _plain3x3(m) and m.in_channels == 64 and m.out_channels <= 4 and not relu:   # tail
@@ -246,11 +290,18 @@ class FFDNet(_PlainStack):
         return x[..., :h, :w]
 
 
-def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1, math='f32'):
+def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1, math='f32', fmt=0):
     import ctypes as C
     from . import _lib
     out = torch.empty_like(x_nhwc)
     n, H, W, ch = x_nhwc.shape
+    if math == 'f16x3':
+        _check_range(x_nhwc, bool(fmt & FMT_X), 'a %d-channel conv3x3' % ch)
+    if fmt:                                                        # f16x3 only: tensors in the split activation format
+        _lib.check(L.pnp_conv3x3_nhwc_f16x3_fmt(
+            stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()), None if bias is None else C.c_void_p(bias.data_ptr()),
+            None if skip_nhwc is None else C.c_void_p(skip_nhwc.data_ptr()), C.c_void_p(out.data_ptr()), n, ch, H, W, 1 if relu else 0, int(dilation), int(fmt)))
+        return out
     if ch != 64:                                                   # DRUNet's 128- / 256- / 512-channel blocks: f16x3 only (_hip_body_ok)
         _lib.check(L.pnp_conv3x3_nhwc_f16x3(
             stream, C.c_void_p(x_nhwc.data_ptr()), C.c_void_p(packed.data_ptr()), None if bias is None else C.c_void_p(bias.data_ptr()),
@@ -277,8 +328,11 @@ class _ResBlock(nn.Module):
         return (self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0], _hip_math(self.backend))
                 and _hip_body_ok(self.res[2], _hip_math(self.backend)))
 
-    def forward_nhwc(self, xn):
-        """the block on a contiguous [n][H][W][C] tensor, on libpnpmri.so (hip_ok() must hold)"""
+    def forward_nhwc(self, xn, in_split=False, out_split=False):
+        """the block on a contiguous [n][H][W][C] tensor, on libpnpmri.so (hip_ok() must hold).  Under 'hip_f16x3' the tensor between
+        the block's two convolutions is in the split activation format (the first convolution splits its outputs once, the second
+        copies halves into its operand tile); in_split / out_split: so are the block's input / output -- a chain of blocks hands
+        split tensors from one to the next."""
         import ctypes as C
         from . import _lib
         if not (xn.is_cuda and xn.dtype == torch.float32):
@@ -286,8 +340,13 @@ class _ResBlock(nn.Module):
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(xn.device).cuda_stream)
         math = _hip_math(self.backend)
-        h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream, math), self.res[0].bias, None, True, 1, math)
-        return _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream, math), self.res[2].bias, xn, False, 1, math)
+        f16 = math == 'f16x3'
+        if (in_split or out_split) and not f16:
+            raise ValueError('the split activation format belongs to the f16x3 kernels')
+        f0 = (FMT_Y | (FMT_X if in_split else 0)) if f16 else 0
+        f2 = (FMT_X | (FMT_SKIP if in_split else 0) | (FMT_Y if out_split else 0)) if f16 else 0
+        h = _hip_conv64(L, stream, xn, _hip_weights(self.res, 0, self.res[0], L, stream, math), self.res[0].bias, None, True, 1, math, f0)
+        return _hip_conv64(L, stream, h, _hip_weights(self.res, 2, self.res[2], L, stream, math), self.res[2].bias, xn, False, 1, math, f2)
 
     def forward(self, x):
         if self.hip_ok():
@@ -367,23 +426,23 @@ class UNetRes(nn.Module):
             _lib.check((L.pnp_convT2x2s2_nhwc_f16x3 if up else L.pnp_conv2x2s2_nhwc_f16x3)(stream, ptr(t), ptr(t2), ptr(wp), ptr(out), nn_, c, h, w))
             return out
 
+        def blocks(ms, t):
+            """a run of residual blocks: float32 in, float32 out, split tensors in between"""
+            for k, m in enumerate(ms):
+                t = m.forward_nhwc(t, in_split=k > 0, out_split=k + 1 < len(ms))
+            return t
+
         def down(seq, t):
-            for m in seq[:-1]:
-                t = m.forward_nhwc(t)
-            return scale(seq[-1], t, None, False)
+            return scale(seq[-1], blocks(seq[:-1], t), None, False)
 
         def up(seq, t, skip):
             t = scale(seq[0], t, skip, True)                   # m_up(x + x_skip): the sum is formed while the operand is staged
-            for m in seq[1:]:
-                t = m.forward_nhwc(t)
-            return t
+            return blocks(seq[1:], t)
 
         x2 = down(self.m_down1, x1)
         x3 = down(self.m_down2, x2)
         x4 = down(self.m_down3, x3)
-        x = x4
-        for m in self.m_body:
-            x = m.forward_nhwc(x)
+        x = blocks(self.m_body, x4)
         x = up(self.m_up3, x, x4)
         x = up(self.m_up2, x, x3)
         x = up(self.m_up1, x, x2)

@@ -415,3 +415,62 @@ def test_graph_and_eager_calls_of_one_denoiser_each_use_their_own_sigma(env):
     den(small, 2)
     den.graph = False
     assert _rel(den(small, 0), ref(small, 0)) <= 1e-5
+
+
+@pytest.mark.parametrize('ch,n,H,W,dil', [(64, 3, 40, 56, 1), (64, 2, 5, 23, 3), (128, 2, 24, 24, 1), (256, 1, 17, 9, 1)])
+@pytest.mark.parametrize('fmt', [1, 2, 3, 4, 5, 6, 7])
+def test_f16x3_layer_with_tensors_in_the_split_activation_format(env, ch, n, H, W, dil, fmt):
+    """pnp_conv3x3_nhwc_f16x3_fmt: any of x / skip / y in the split activation format ([64 hi halves][64 lo halves] per block of 64
+    channels; include/pnp_mri.h).  A split INPUT carries exactly the operand values the layer would have formed itself, so the result
+    equals the all-float32 call bit for bit; a split SKIP is the float32 one rounded to 2^-22; a split OUTPUT is the float32 result
+    rounded to 2^-22 (an absolute 2.4e-7 of the tensor's scale at most) -- and against float64 the layer stays at the tolerance of
+    the float32-format one (2e-6)."""
+    torch, F, L, lib, D = env['torch'], env['F'], env['L'], env['lib'], env['D']
+    g = torch.Generator(device='cuda').manual_seed(7 * ch + fmt)
+    x = torch.randn(n, H, W, ch, device='cuda', generator=g)
+    skip = torch.randn(n, H, W, ch, device='cuda', generator=g)
+    w = torch.randn(ch, ch, 3, 3, device='cuda', generator=g) * (2.0 / (9 * ch)) ** 0.5
+    bias = torch.randn(ch, device='cuda', generator=g) * 0.1
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    wp = torch.empty(9 * ch * ch, device='cuda')
+    lib.check(L.pnp_conv3x3_pack_f16x3(s, p(w), p(wp), ch))
+    x_q = D.unsplit_activations(D.split_activations(x))           # what a split tensor can hold
+    assert _rel(x_q, x) <= 3e-7 and _rel(D.unsplit_activations(D.split_activations(x * 1e-3)), x * 1e-3) <= 3e-7
+    xin = D.split_activations(x) if fmt & 1 else x
+    kin = D.split_activations(skip) if fmt & 2 else skip
+    y = torch.full_like(x, float('nan'))
+    lib.check(L.pnp_conv3x3_nhwc_f16x3_fmt(s, p(xin), p(wp), p(bias), p(kin), p(y), n, ch, H, W, 1, dil, fmt))
+    got = D.unsplit_activations(y) if fmt & 4 else y
+    assert bool(torch.isfinite(got).all())
+    ref = torch.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=dil, dilation=dil).permute(0, 2, 3, 1) + skip.double())
+    assert _rel(got, ref) <= 2e-6, _rel(got, ref)
+    # against the all-float32-format call on the values the split tensors really hold
+    y0 = torch.empty_like(x)
+    k_q = D.unsplit_activations(kin) if fmt & 2 else skip
+    lib.check(L.pnp_conv3x3_nhwc_f16x3_fmt(s, p(x), p(wp), p(bias), p(k_q), p(y0), n, ch, H, W, 1, dil, 0))
+    if fmt == 1:
+        assert torch.equal(got, y0)                                # same operands, same epilogue: the same bits
+    else:
+        # the split-format epilogue adds the bias before the skip value, the float32 one after: one rounding apart at most -- plus, for a
+        # split output, its own rounding to 2^-22
+        want = D.unsplit_activations(D.split_activations(y0)) if fmt & 4 else y0
+        assert float((got - want).abs().max()) <= 3.5e-7 * float(want.abs().max()) + 1e-7, float((got - want).abs().max())
+    with pytest.raises(lib.PnpError):
+        lib.check(L.pnp_conv3x3_nhwc_f16x3_fmt(s, p(x), p(wp), p(bias), p(kin), p(y), n, ch, H, W, 1, dil, 8))
+
+
+def test_conv_check_range_knob(env, monkeypatch):
+    """PNP_CONV_CHECK_RANGE=1: an activation beyond the half range entering an f16x3 layer raises at that layer (bring-up with real
+    weights) instead of surfacing as NaN at the end of the network"""
+    torch, D = env['torch'], env['D']
+    net, nlm, _ = D.build('dncnn_15')
+    sd = D.seeded_state_dict(net, 3)
+    sd['model.0.weight'][0, 0, 1, 1] = 1e6
+    net.load_state_dict(sd)
+    den = D.Denoiser('dncnn_15', net.eval(), nlm, backend='hip_f16x3').to('cuda')
+    x = torch.rand(2, 1, 32, 32, device='cuda')
+    assert not bool(torch.isfinite(den(x, 0)).all())              # without the knob: loud only at the output
+    monkeypatch.setenv('PNP_CONV_CHECK_RANGE', '1')
+    with pytest.raises(FloatingPointError):
+        den(x, 0)
