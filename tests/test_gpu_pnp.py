@@ -293,6 +293,10 @@ def test_pnp_admm_cnc_d_fifty_iterations_golden(env50, golden_inputs, tag, backe
     S6:289-298) on Q_Random30, plus the mask + model pairs of BASELINE.json configs[2] (FFDNet, Q_Radial30) and configs[3] (DRUNet,
     Q_Cartesian30)."""
     from conftest import weights50
+    if tag == 'cnc_d_drunet_gray_cartesian30' and backend != 'hip_f16x3':
+        # DRUNet's one-slice forwards cost ~1 s each where MIOpen runs them on a fresh box (100 per run): the PyTorch and fp32-MFMA
+        # backends are held to the DRUNet golden on Q_Random30 above; config 4's mask is run on the backend config 4 is benchmarked with
+        pytest.skip('DRUNet on MIOpen is covered by the Q_Random30 case (95 s per run)')
     parts = tag[len('cnc_d_'):].split('_')
     name = '_'.join(parts[:2])
     mask = golden_inputs['masks'][MASK_OF.get(parts[-1], 'Q_Random30')].astype(np.float64)
