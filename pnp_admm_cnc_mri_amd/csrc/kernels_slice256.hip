@@ -364,7 +364,10 @@ __device__ __forceinline__ void store_x_natural(const SliceBufs& b, const c32 (&
 }
 
 // all four register sets of a wave; loads of set s + 1 are in flight during the transforms around them
-template <int PROX> constexpr int row_pf() { return (PROX == 3) ? 8 : SLICE_PF; }
+#ifndef SLICE_L1_PF
+#define SLICE_L1_PF 8       // ADMM_L1's single-state form (PROX 3): ALL eight accesses of the next set are in flight across this set's forward and the
+#endif                      // next set's inverse transform -- the overlap the form's 8 N fewer bytes leave room for (experiment knob: 4, 2 = less of it)
+template <int PROX> constexpr int row_pf() { return (PROX == 3) ? SLICE_L1_PF : SLICE_PF; }
 // the first accesses of set 0, issued by the caller ahead of the phase (SLICE_EARLY: between the two passes of T2)
 template <int PROX, bool HAS_INV>
 __device__ __forceinline__ void row_phase_prefetch(const SliceBufs& b, RowLoads& L, int wv, int lane) {
