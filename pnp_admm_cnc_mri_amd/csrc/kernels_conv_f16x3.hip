@@ -15,8 +15,8 @@
 //
 // Structure (the float32 kernel's, conv_common.h, where it still fits): persistent 256-thread workgroups, two per compute
 // unit at dilation 1 (80 KiB of LDS each; one at dilations 2..4: 98 .. 137 KiB), 8 x 16 output pixels x 64 output channels per ITEM, the input tile (halo included) of 64 input channels in LDS for nine
-// taps -- already split: a pixel is [64 hi halves][64 lo halves] + 16 bytes, so an operand fragment (8 consecutive channels of a
-// pixel) is one ds_read_b128.  What differs:
+// taps -- already split: a pixel is 128 hi + 128 lo halves + 16 bytes in a bank-conflict-free chunk order (f16x3_common.h), so an operand
+// fragment (8 consecutive channels of a pixel) is one ds_read_b128.  What differs:
 //   instruction   v_mfma_f32_16x16x32_f16 (the 32x32x16 form does the same arithmetic in the same cycles 7 % slower: under the power
 //                 limit the narrow form holds the higher clock); a wave = 2 M tiles (its two tile rows) x 4 N tiles, main and
 //                 correction accumulators: 64 registers
@@ -106,21 +106,25 @@ __device__ __forceinline__ void fetch_input_p(const ConvArgs& a, const TilePos& 
 template <int DIL>
 __device__ __forceinline__ void put_input_h3(float* xin, int tid, const f32x4 (&v)[Geo<DIL>::XU], const bool in_split = false) {
     if (in_split) {
-        char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + 16 * (tid & 15);
+        // chunk q = tid & 15 of the tensor's pixel: hi halves of channels 8 q .. (q < 8) or lo halves of channels 8 (q - 8) ..
+        const int q = tid & 15;
+        char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + h3_chunk_pos(q & 3, (q >> 2) & 1, q >> 3);
 #pragma unroll
         for (int u = 0; u < Geo<DIL>::XU; ++u)
             if (stage_pixel(tid) + 16 * u < Geo<DIL>::HY * Geo<DIL>::HX)
                 *reinterpret_cast<f32x4*>(px + u * (16 * CV_PS * 4)) = v[u];
         return;
     }
-    char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + 8 * (tid & 15);
+    // float32 input: this thread's four channels 4 t .. (t = tid & 15) are half of chunk (kb = (t >> 1) & 3, s2 = t >> 3)
+    const int t = tid & 15;
+    char* px = reinterpret_cast<char*>(xin) + stage_pixel(tid) * (CV_PS * 4) + h3_chunk_pos((t >> 1) & 3, t >> 3, 0) + 8 * (t & 1);
 #pragma unroll
     for (int u = 0; u < Geo<DIL>::XU; ++u)
         if (stage_pixel(tid) + 16 * u < Geo<DIL>::HY * Geo<DIL>::HX) {
             h4 hi, lo;
             split4(v[u], hi, lo);
             *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4)) = hi;
-            *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4) + 128) = lo;
+            *reinterpret_cast<h4*>(px + u * (16 * CV_PS * 4) + 16) = lo;      // part 1 = the chunk behind part 0
         }
 }
 
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define H3_LOAD_A(slot, ap_, s2_)                                                                        \
             _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                           \
-                ah[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 64 * (s2_));        \
-                al[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 64 * (s2_) + 128);  \
+                ah[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 32 * (s2_));        \
+                al[slot][mt] = *reinterpret_cast<const h8*>((ap_) + mt * (HX * CV_PS * 4) + 32 * (s2_) + 16);   \
             }
 #define H3_LOAD_B(slot, h_)                                                                              \
             _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                           \
@@ -290,8 +294,9 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                 corrv[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[((h_) >> 1) & 1][mt], bh[(h_) & 1][q_], corrv[mt][nt_], 0, 0, 0);  \
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);
-            // tap (0, 0), M tile 0: pixel (row 2 w, column i); + HX pixels: M tile 1; + 64 s2: K step; + 128: the lo halves
-            const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + i) * (CV_PS * 4) + kb * 16;
+            // tap (0, 0), M tile 0: pixel (row 2 w, column h3_row_pixel(i)); + HX pixels: M tile 1; + 32 s2: K step; + 16: the lo halves
+            // (the conflict-free chunk order of f16x3_common.h)
+            const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + h3_row_pixel(i)) * (CV_PS * 4) + h3_chunk_pos(kb, 0, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
             asm volatile("" ::: "memory");
             H3_STAMP(5)
             if (last) {
-                // accumulator (reg r, lane (i, kb)) of tile (mt, nt) = pixel (tile row mt of the wave, column 4 kb + r), channel 16 nt + i:
+                // accumulator (reg r, lane (i, kb)) of tile (mt, nt) = M-tile row 4 kb + r = pixel (tile row mt of the wave, column h3_row_pixel(4 kb + r)), channel 16 nt + i:
                 // into the wave's staging rows (pixel order, 68 floats apart: the four lane groups of a write start 16 banks apart)
                 float* stage = xin + wv * (32 * H3_STR);
 #ifndef H3_ABL_NOEPI
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(CV_THREADS, GeoH<DIL>::WPS) void k_conv3x3_c64_h3(C
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            stage[(16 * mt + 4 * kb + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]) + bs[nt];
+                            stage[(16 * mt + h3_row_pixel(4 * kb) + r) * H3_STR + 16 * nt + i] = fmaf(corrv[mt][nt][r], H3_RSCALE, mainv[mt][nt][r]) + bs[nt];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a wave's LDS instructions execute in order: compiler-only ordering
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
     f32x4 mainv[2], corrv[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) { mainv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; corrv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + i) * (CV_PS * 4) + kb * 16;
+    const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + h3_row_pixel(i)) * (CV_PS * 4) + h3_chunk_pos(kb, 0, 0);
     const char* const b0 = reinterpret_cast<const char*>(wl) + kb * 64 + (i & 3) * 16;
     const bool col = i < t.cout;
     const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -489,15 +494,15 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
             bh = col ? bh : zero; bl = col ? bl : zero;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const h8 ah = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 64 * s2);
-                const h8 al = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 64 * s2 + 128);
+                const h8 ah = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 32 * s2);
+                const h8 al = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 32 * s2 + 16);
                 mainv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, mainv[mt], 0, 0, 0);
                 corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, corrv[mt], 0, 0, 0);
                 corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, corrv[mt], 0, 0, 0);
             }
         }
     }
-    // accumulator (reg r, lane (i, kb)) of M tile mt = pixel (tile row 2 w + mt, column 4 kb + r), output channel i
+    // accumulator (reg r, lane (i, kb)) of M tile mt = pixel (tile row 2 w + mt, column h3_row_pixel(4 kb + r)), output channel i
     if (col) {
         const float b = t.bias ? t.bias[i] : 0.f;
         const size_t plane = (size_t)t.H * t.W;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
             const int gy = q.y0 + 2 * wv + mt;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gx = q.x0 + 4 * kb + r;
+                const int gx = q.x0 + h3_row_pixel(4 * kb) + r;
                 if (gy < t.H && gx < t.W)
                     t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
             }
