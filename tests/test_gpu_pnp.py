@@ -264,17 +264,6 @@ def env50(env):
     return dict(env, known50=known, gold50=np.load(os.path.join(GOLD, 'pnp50_set1_05.npz')))
 
 
-def _miopen(env50, name, backend, monkeypatch):
-    """DRUNet's one-slice convolutions where MIOpen runs them (the PyTorch backend; the 128 .. 512-channel blocks of backend 'hip'): in
-    immediate mode under the module's deterministic flag a forward takes ~1 s on a fresh box -- 100 forwards per run.  A find (a few
-    seconds per shape, cached for the process) brings that to milliseconds; with contractive weights the run-to-run differences of the
-    kernels it picks stay far below the 1e-5 of these tests."""
-    if name == 'drunet_gray' and backend != 'hip_f16x3':
-        monkeypatch.setattr(env50['torch'].backends.cudnn, 'deterministic', False)
-        return dict(miopen_find=True)
-    return {}
-
-
 def _check50(out, ref, gray, line, fmt):
     err = rel_l2(out, ref)
     assert err <= 1e-5, err
@@ -288,15 +277,13 @@ def _check50(out, ref, gray, line, fmt):
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('tag', ['cnc_d_ffdnet_gray', 'cnc_d_fdncnn_gray', 'cnc_d_drunet_gray', 'cnc_d_ircnn_gray',
                                  'cnc_d_ffdnet_gray_radial30', 'cnc_d_drunet_gray_cartesian30'])
-def test_pnp_admm_cnc_d_fifty_iterations_golden(env50, golden_inputs, tag, backend, tmp_path, monkeypatch):
+def test_pnp_admm_cnc_d_fifty_iterations_golden(env50, golden_inputs, tag, backend, tmp_path):
     """PNP_ADMM_CNC_D at its committed presets (S6:569-577): FFDNet / FDnCNN / DRUNet / IRCNN (25-model bank, switched by sigma_i as in
     S6:289-298) on Q_Random30, plus the mask + model pairs of BASELINE.json configs[2] (FFDNet, Q_Radial30) and configs[3] (DRUNet,
     Q_Cartesian30)."""
     from conftest import weights50
-    if tag == 'cnc_d_drunet_gray_cartesian30' and backend != 'hip_f16x3':
-        # DRUNet's one-slice forwards cost ~1 s each where MIOpen runs them on a fresh box (100 per run): the PyTorch and fp32-MFMA
-        # backends are held to the DRUNet golden on Q_Random30 above; config 4's mask is run on the backend config 4 is benchmarked with
-        pytest.skip('DRUNet on MIOpen is covered by the Q_Random30 case (95 s per run)')
+    if 'drunet' in tag and backend != 'hip_f16x3':
+        pytest.skip('DRUNet on the MIOpen-backed backends: test_drunet_fifty_iterations_on_the_miopen_backends_in_a_fresh_process')
     parts = tag[len('cnc_d_'):].split('_')
     name = '_'.join(parts[:2])
     mask = golden_inputs['masks'][MASK_OF.get(parts[-1], 'Q_Random30')].astype(np.float64)
@@ -304,7 +291,7 @@ def test_pnp_admm_cnc_d_fifty_iterations_golden(env50, golden_inputs, tag, backe
     opts['iter_num'] = int(opts['iter_num'])
     assert opts['iter_num'] == 50
     out, psnr1 = env50['S'].PNP_ADMM_CNC_D(name, mask, golden_inputs['noises'], images=golden_inputs['gray'][None], model=weights50(name),
-                                           results=str(tmp_path), cnn_backend=backend, **_miopen(env50, name, backend, monkeypatch), **opts)
+                                           results=str(tmp_path), cnn_backend=backend, **opts)
     _check50(out[0], env50['gold50'][tag], golden_inputs['gray'], env50['known50'][tag], '%.4f')
     assert abs(psnr1[0] - O.calculate_psnr(np.round(out[0] * 255), golden_inputs['gray'])) <= 1e-4
 
@@ -331,13 +318,36 @@ def test_pnp_admm_cnc_dncnn_pair_fifty_iterations_golden(env50, golden_inputs, b
 
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('name', ['ffdnet_gray', 'dncnn_15', 'fdncnn_gray', 'drunet_gray', 'ircnn_gray'])
-def test_pnp_admm_l1_d_fifty_iterations_golden(env50, golden_inputs, name, backend, tmp_path, monkeypatch):
+def test_pnp_admm_l1_d_fifty_iterations_golden(env50, golden_inputs, name, backend, tmp_path):
     """PNP_ADMM_L1_D at its presets (S3:339-347); DRUNet and FFDNet walk the x8 cycle six times (S3:40-50)."""
     from conftest import weights50
+    if name == 'drunet_gray' and backend != 'hip_f16x3':
+        pytest.skip('DRUNet on the MIOpen-backed backends: test_drunet_fifty_iterations_on_the_miopen_backends_in_a_fresh_process')
     opts = dict(env50['known50']['l1_d_%s_opts' % name])
     opts['iter_num'] = int(opts['iter_num'])
     assert opts['iter_num'] == 50
     mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
     out = env50['S'].PNP_ADMM_L1_D(name, mask, golden_inputs['noises'], images=golden_inputs['gray'][None], model=weights50(name),
-                                   results=str(tmp_path), cnn_backend=backend, **_miopen(env50, name, backend, monkeypatch), **opts)
+                                   results=str(tmp_path), cnn_backend=backend, **opts)
     _check50(out[0], env50['gold50']['l1_d_' + name], golden_inputs['gray'], env50['known50']['l1_d_' + name], '%.2f')
+
+
+def test_drunet_fifty_iterations_on_the_miopen_backends_in_a_fresh_process():
+    """DRUNet's three 50-iteration goldens (CNC_D on Q_Random30 and on config 4's Q_Cartesian30, L1_D with the x8 cycle) on the backends
+    where MIOpen runs (part of) the forward -- 'torch' and 'hip' -- in a FRESH process with MIOpen's find mode on: in this test process the
+    deterministic flag of the module fixture has already sent those convolution shapes through MIOpen's immediate mode, after which
+    a one-slice forward stays at ~1 s whatever is asked later (600 forwards = 10 minutes; the fresh process needs a few seconds:
+    profiles/experiments/miopen_immediate_vs_find.py).  Same entry points, same bar: 1e-5, PSNR within 0.01 dB of the authors' line."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    tags = ['cnc_d_drunet_gray', 'cnc_d_drunet_gray_cartesian30', 'l1_d_drunet_gray']
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'profiles', 'experiments', 'pnp50_measured.py'), 'torch', 'hip', '--tags'] + tags,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('JSON ')][-1][5:])
+    assert sorted((e['tag'], e['backend']) for e in res) == sorted((t, b) for t in tags for b in ('torch', 'hip'))
+    for e in res:
+        assert e['rel_l2'] <= 1e-5, e
+        assert abs(e['psnr'] - e['psnr_golden']) <= 0.01, e
+        assert abs(e['psnr'] - float(e['log_line'].split('PSNR:')[1].split('dB')[0])) <= 0.01, e
