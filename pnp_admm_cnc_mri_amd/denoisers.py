@@ -201,7 +201,7 @@ def hip_stack_forward(seq, x, math='f32'):
             if math == 'f16x3':
                 # a body layer followed by another body layer hands its result over in the split activation format
                 kn = k + (2 if relu else 1)
-                out_split = kn < len(mods) and _hip_body_ok(mods[kn], math)
+                out_split = kn < len(mods) and _hip_body_ok(mods[kn])          # the SAME test the branch above applies to the next layer
                 nhwc = _hip_conv64(L, stream, nhwc, _hip_weights(seq, k, m, L, stream, math), m.bias, None, relu, m.dilation[0], math,
                                    (FMT_X if nhwc_split else 0) | (FMT_Y if out_split else 0))
                 nhwc_split = out_split
