@@ -192,35 +192,39 @@ def claim_stdout():
 
 def pnp_record(steps=3, warmup=1, total_timeout=300):
     """BASELINE.json configs[2] (PNP_ADMM_CNC_D, FFDNet-gray, 512 slices of 256 x 256, Q_Radial30) measured by bench_pnp.py in two
-    child processes AFTER this process has released its engine and buffers: the CNN forward on PyTorch-ROCm / MIOpen (the north
+    child processes -- plus configs[3]'s per-GPU shard (DRUNet-gray, Q_Cartesian30) on the f16x3 backend in a third -- AFTER this process
+    has released its engine and buffers: the CNN forward on PyTorch-ROCm / MIOpen (the north
     star's split) and on libpnpmri.so's split-half f16 matrix-core kernels (`cnn_backend='hip_f16x3'`).  Each child's
     line carries its own parity record (three slices of the timed run against the oracle's loop) and its physical roofline (the matrix
-    products really issued against the peak of the pipe that runs them).  A sub-record: it never fails the main line; both children
+    products really issued against the peak of the pipe that runs them).  A sub-record: it never fails the main line; the children
     share ONE time budget, and the tail of a failed child's stderr is kept."""
     import subprocess
     rec = {'config': 'configs[2]: PNP_ADMM_CNC_D, FFDNet-gray, 512 x 256x256 slices, Q_Radial30, S6:573 presets (bench_pnp.py --steps %d --warmup %d)'
                      % (steps, warmup), 'unit': 'it/s (512-slice batches)'}
     deadline = time.monotonic() + total_timeout
-    for backend in ('torch', 'hip_f16x3'):
+    # third child: BASELINE.json configs[3]'s per-GPU shard (DRUNet-gray, 512 slices, Q_Cartesian30) on the f16x3 backend -- every layer of the
+    # U-Net on libpnpmri.so; its PyTorch / MIOpen counterpart needs a two-minute find on a fresh box and stays with bench_pnp.py
+    for key, model, backend, st in (('torch', 'ffdnet_gray', 'torch', steps), ('hip_f16x3', 'ffdnet_gray', 'hip_f16x3', steps),
+                                    ('config4_shard_drunet_hip_f16x3', 'drunet_gray', 'hip_f16x3', max(1, steps - 1))):
         err = b''
         try:
             left = deadline - time.monotonic()
             if left < 20:
                 raise TimeoutError('the record\'s time budget of %d s is spent' % total_timeout)
-            r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', 'ffdnet_gray', '--batch', '512', '--steps', str(steps),
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', model, '--batch', '512', '--steps', str(st),
                                 '--warmup', str(warmup), '--cnn-backend', backend], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                timeout=left, cwd=ROOT)
             err = r.stderr
             j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
             rf = j['denoiser']['roofline']
-            rec[backend] = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'denoiser_ms_per_step': j['denoiser']['ms_per_step'],
-                            'denoiser_roofline': {k: rf[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_fp32_equivalent')},
-                            'parity': j['parity'], 'weights': j['config']['weights'],
-                            'x_finite': j['x_finite'], 'denoiser_outputs_finite': j['denoiser_outputs_finite']}
+            rec[key] = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'denoiser_ms_per_step': j['denoiser']['ms_per_step'],
+                        'denoiser_roofline': {k: rf[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_fp32_equivalent')},
+                        'parity': j['parity'], 'weights': j['config']['weights'], 'workload': j['config']['workload'],
+                        'x_finite': j['x_finite'], 'denoiser_outputs_finite': j['denoiser_outputs_finite']}
         except subprocess.TimeoutExpired as e:
-            rec[backend] = {'error': 'timeout', 'stderr_tail': (e.stderr or b'').decode(errors='replace')[-600:]}
+            rec[key] = {'error': 'timeout', 'stderr_tail': (e.stderr or b'').decode(errors='replace')[-600:]}
         except Exception as e:                                       # noqa: BLE001 -- a failed child is reported, not raised
-            rec[backend] = {'error': repr(e)[:300], 'stderr_tail': err.decode(errors='replace')[-600:]}
+            rec[key] = {'error': repr(e)[:300], 'stderr_tail': err.decode(errors='replace')[-600:]}
     if 'value' in rec.get('torch', {}) and 'value' in rec.get('hip_f16x3', {}):
         rec['speedup'] = rec['hip_f16x3']['value'] / rec['torch']['value']
     rec['note'] = ('hip_f16x3: float32 operands carried as two halves, three exact-product f16 matrix instructions per product, float32 '
@@ -249,7 +253,7 @@ def main():
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)),
                     help='--gpus N without torchrun: seconds after which hanging rank processes are killed (exit 124)')
     ap.add_argument('--no-pnp-record', action='store_true',
-                    help='skip the `pnp` sub-record (configs[2]: FFDNet PnP on the PyTorch / MIOpen backend and on the f16x3 HIP backend, two child runs of bench_pnp.py, ~40 s)')
+                    help='skip the `pnp` sub-record (configs[2]: FFDNet PnP on the PyTorch / MIOpen backend and on the f16x3 HIP backend, configs[3] shard: DRUNet on the f16x3 backend; three child runs of bench_pnp.py, ~60 s)')
     ap.add_argument('--no-l1-record', action='store_true',
                     help="skip the `l1` sub-record (ADMM_L1, configs[0]'s solver with the S1:171 presets, on the same batch; N = 1, headline configuration only)")
     ap.add_argument('--no-f64-record', action='store_true',

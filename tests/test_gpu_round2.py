@@ -79,8 +79,9 @@ def test_bench_pnp_sub_record():
     sys.path.insert(0, ROOT)
     import bench
     rec = bench.pnp_record(steps=1, warmup=1)
-    assert set(rec) >= {'config', 'unit', 'torch', 'hip_f16x3', 'speedup', 'note'}, rec
-    for b in ('torch', 'hip_f16x3'):
+    assert set(rec) >= {'config', 'unit', 'torch', 'hip_f16x3', 'config4_shard_drunet_hip_f16x3', 'speedup', 'note'}, rec
+    assert 'drunet_gray' in rec['config4_shard_drunet_hip_f16x3']['workload'] and 'Q_Cartesian30' in rec['config4_shard_drunet_hip_f16x3']['workload']
+    for b in ('torch', 'hip_f16x3', 'config4_shard_drunet_hip_f16x3'):
         assert 'error' not in rec[b] and rec[b]['x_finite'] and rec[b]['denoiser_outputs_finite'] and rec[b]['value'] > 0, rec[b]
         # every child re-proves parity of what it timed: three slices against the oracle's loop with the same denoiser
         assert rec[b]['parity']['slices'] == [0, 255, 511] and max(rec[b]['parity']['rel_l2_vs_oracle']) <= 1e-5, rec[b]['parity']
