@@ -3,10 +3,11 @@
 assertions of tests/test_gpu_pnp.py.  Also the FRESH PROCESS in which that file runs DRUNet on the MIOpen-backed backends: once MIOpen has
 served a convolution shape in immediate mode under torch's deterministic flag (the rest of that test module needs it), a later find in the same
 process no longer helps -- a one-slice DRUNet forward stays at ~1 s (naive kernels) where a fresh process with find enabled needs 20 ms
-(profiles/experiments/miopen_immediate_vs_find.py).  usage (GPU box): python3 profiles/experiments/pnp50_measured.py [backends...] [--tags tag ...]"""
+(profiles/experiments/miopen_immediate_vs_find.py).  TEST INFRASTRUCTURE (it checks against tests/golden and uses the oracle's PSNR).
+usage (GPU box): python3 tests/pnp50_runner.py [backends...] [--tags tag ...]"""
 import json, os, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from conftest import weights50, GOLD
@@ -14,7 +15,7 @@ from pnp_admm_cnc_mri_amd import solvers_pnp as S
 from oracle import admm_oracle as O
 args = sys.argv[1:]
 only = None
-if '--tags' in args:                                   # pnp50_measured.py [backends...] --tags tag [tag ...]
+if '--tags' in args:                                   # pnp50_runner.py [backends...] --tags tag [tag ...]
     k = args.index('--tags')
     only, args = set(args[k + 1:]), args[:k]
 backends = args or ['torch', 'hip', 'hip_f16x3']

@@ -342,7 +342,7 @@ def test_drunet_fifty_iterations_on_the_miopen_backends_in_a_fresh_process():
     import sys
     from conftest import ROOT
     tags = ['cnc_d_drunet_gray', 'cnc_d_drunet_gray_cartesian30', 'l1_d_drunet_gray']
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'profiles', 'experiments', 'pnp50_measured.py'), 'torch', 'hip', '--tags'] + tags,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'pnp50_runner.py'), 'torch', 'hip', '--tags'] + tags,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('JSON ')][-1][5:])
