@@ -267,6 +267,16 @@ int pnp_conv3x3_head_nhwc(void* hip_stream, const float* x_nchw_dev, const float
                           float* y_nhwc_dev, int n, int cin, int H, int W, int relu);
 int pnp_conv3x3_tail_nchw(void* hip_stream, const float* x_nhwc_dev, const float* w_oihw_dev, const float* bias_dev,
                           float* y_nchw_dev, int n, int cout, int H, int W);
+/* FFDNet's input and output stages folded into its first and last layer (models/network_ffdnet.py:58-73): no pad / pixel-unshuffle / concatenation
+ * / pixel-shuffle / crop launches and no intermediate tensors around the stack.
+ *   pnp_ffdnet_head_nhwc   x [n][1][h][w] (full resolution, any h, w >= 1: odd sizes are replicate-padded as the reference does), sigma_dev [n] or [1]
+ *                          (sigma_per_image = 1 / 0): the layer's five input channels are the four pixel-unshuffled quarters of x and the noise
+ *                          level; w a torch Conv2d(5, 64, 3) weight -> y [n][ceil(h/2)][ceil(w/2)][64] (NHWC), + bias, ReLU
+ *   pnp_ffdnet_tail_f16x3  x [n][ceil(h/2)][ceil(w/2)][64] (NHWC), w a torch Conv2d(64, 4, 3) weight -> y [n][1][h][w]: the four output channels
+ *                          written pixel-shuffled and cropped, in the f16x3 arithmetic of pnp_conv3x3_tail_nchw_f16x3.   New in ABI 10. */
+int pnp_ffdnet_head_nhwc(void* hip_stream, const float* x_dev, const float* sigma_dev, int sigma_per_image, const float* w_oihw_dev,
+                         const float* bias_dev, float* y_nhwc_dev, int n, int h, int w, int relu);
+int pnp_ffdnet_tail_f16x3(void* hip_stream, const float* x_nhwc_dev, const float* w_oihw_dev, const float* bias_dev, float* y_dev, int n, int h, int w);
 /* [n][64][H][W] <-> [n][H][W][64] (to_nhwc = 1 / 0): hand-over between PyTorch layers (NCHW) and the kernels above. */
 int pnp_relayout_c64(void* hip_stream, const float* in_dev, float* out_dev, int n, int H, int W, int to_nhwc);
 

@@ -75,6 +75,8 @@ SIGNATURES = {
     'pnp_conv2x2s2_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_convT2x2s2_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv2x2_pack_f16x3': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    'pnp_ffdnet_head_nhwc': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_ffdnet_tail_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_head_nhwc': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_tail_nchw': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_relayout_c64': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),

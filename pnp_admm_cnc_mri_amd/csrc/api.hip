@@ -971,6 +971,19 @@ int pnp_conv3x3_tail_add_nchw_f16x3(void* stream, const float* x, const float* x
     HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, x2, w, bias, y, n, cout, H, W));
     return PNP_OK;
 }
+int pnp_ffdnet_head_nhwc(void* stream, const float* x, const float* sigma, int sigma_per_image, const float* w, const float* bias, float* y,
+                         int n, int h, int wd, int relu) {
+    if (!x || !sigma || !w || !y) return fail(PNP_E_ARG, "pnp_ffdnet_head_nhwc: null pointer");
+    if (n < 1 || h < 1 || wd < 1) return fail(PNP_E_ARG, "pnp_ffdnet_head_nhwc: n, h, w must be >= 1");
+    HIPCHK(launch_ffdnet_head((hipStream_t)stream, x, sigma, sigma_per_image != 0, w, bias, y, n, h, wd, relu));
+    return PNP_OK;
+}
+int pnp_ffdnet_tail_f16x3(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd) {
+    if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_ffdnet_tail_f16x3: null pointer");
+    if (n < 1 || h < 1 || wd < 1) return fail(PNP_E_ARG, "pnp_ffdnet_tail_f16x3: n, h, w must be >= 1");
+    HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, nullptr, w, bias, y, n, 4, (h + 1) / 2, (wd + 1) / 2, h, wd));
+    return PNP_OK;
+}
 static int pix2_args(const char* who, const float* x, const float* w, const float* y, int n, int C, int H, int W, int up) {
     if (!x || !w || !y) return fail(PNP_E_ARG, "%s: null pointer", who);
     if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "%s: n, H, W must be >= 1", who);

@@ -83,7 +83,10 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfra
                                 float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */,
                                 int fmt = 0 /* bit 0: x, bit 1: skip, bit 2: y in the split activation format (f16x3_common.h) */);
 hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc /* null or added to x */, const float* w_oihw,
-                                     const float* bias, float* y_nchw, int n, int cout, int H, int W);
+                                     const float* bias, float* y_nchw, int n, int cout, int H, int W,
+                                     int shuffle_h = 0, int shuffle_w = 0 /* FFDNet: cout = 4 written as one pixel-shuffled [shuffle_h][shuffle_w] channel */);
+hipError_t launch_ffdnet_head(hipStream_t s, const float* x_full /* [n][1][h][w] */, const float* sigma, int sigma_per_image, const float* w_oihw /* [64][5][3][3] */,
+                              const float* bias, float* y_nhwc /* [n][ceil(h/2)][ceil(w/2)][64] */, int n, int h, int w, int relu);
 // DRUNet's 2 x 2 stride-2 convolution (C -> 2C, up = 0) and 2 x 2 transposed convolution (C -> C/2, up = 1) in the same arithmetic
 // (kernels_pix2x2_f16x3.hip); x2: null or a tensor of x's shape added to it
 hipError_t launch_pix2_pack_w_f16x3(hipStream_t s, const float* w, float* wfrag /* 8 C C floats (down), 2 C C (up) */, int C, int up);

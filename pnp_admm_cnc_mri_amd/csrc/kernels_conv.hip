@@ -259,6 +259,11 @@ constexpr int HD_MAXC = 8;
 struct HeadArgs {
     const float* x; const float* w; const float* bias; float* y;
     int n, cin, H, W, tiles_x, tiles_y, relu;
+    // FFDNet's input stage folded into the staging loop (models/network_ffdnet.py:58-68): x is the FULL-resolution image [n][1][src_h][src_w];
+    // channels 0..3 of the layer's input are its pixel-unshuffled quarters (channel 2 dy + dx at (y, x) = x[2 y + dy][2 x + dx], replicate-padded
+    // to even size = index clamped), channel 4 the noise level sigma[img * sigma_stride]; H = ceil(src_h / 2), W = ceil(src_w / 2)
+    int ffdnet, src_h, src_w, sigma_stride;
+    const float* sigma;
 };
 __global__ __launch_bounds__(256) void k_conv3x3_head(HeadArgs a) {
     __shared__ float xin[HD_MAXC * CV_HY * CV_HX];                 // [ci][row 10][col 18]
@@ -268,12 +273,19 @@ __global__ __launch_bounds__(256) void k_conv3x3_head(HeadArgs a) {
     const int img = blockIdx.x / per_img, trem = blockIdx.x - img * per_img, ty = trem / a.tiles_x;
     const int y0 = ty * CV_TY, x0 = (trem - ty * a.tiles_x) * CV_TX;
     const size_t plane = (size_t)a.H * a.W;
-    const float* xb = a.x + (size_t)img * a.cin * plane;
+    const float* xb = a.ffdnet ? a.x + (size_t)img * a.src_h * a.src_w : a.x + (size_t)img * a.cin * plane;
+    const float sig = a.ffdnet ? a.sigma[(size_t)img * a.sigma_stride] : 0.f;
     for (int e = tid; e < a.cin * CV_HY * CV_HX; e += 256) {
         const int ci = e / (CV_HY * CV_HX), p = e - ci * (CV_HY * CV_HX), r = p / CV_HX, c = p - r * CV_HX;
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
         const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const float v = xb[(size_t)ci * plane + (size_t)(in ? gy : 0) * a.W + (in ? gx : 0)];
+        float v;
+        if (a.ffdnet) {
+            const int sy = min(2 * (in ? gy : 0) + (ci >> 1), a.src_h - 1), sx = min(2 * (in ? gx : 0) + (ci & 1), a.src_w - 1);
+            v = ci < 4 ? xb[(size_t)sy * a.src_w + sx] : sig;      // the convolution zero-pads the noise-level channel too
+        } else {
+            v = xb[(size_t)ci * plane + (size_t)(in ? gy : 0) * a.W + (in ? gx : 0)];
+        }
         xin[e] = in ? v : 0.f;
     }
     for (int e = tid; e < a.cin * 9 * CV_C; e += 256) {            // w_oihw [64][cin][3][3] -> [ci * 9 + tap][out]
@@ -402,6 +414,20 @@ hipError_t launch_conv3x3_head(hipStream_t s, const float* x_nchw, const float* 
     if (cin < 1 || cin > HD_MAXC || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     HeadArgs a;
     a.x = x_nchw; a.w = w_oihw; a.bias = bias; a.y = y_nhwc; a.n = n; a.cin = cin; a.H = H; a.W = W; a.relu = relu;
+    a.ffdnet = 0; a.src_h = a.src_w = a.sigma_stride = 0; a.sigma = nullptr;
+    a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
+    const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv3x3_head, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_ffdnet_head(hipStream_t s, const float* x_full, const float* sigma, int sigma_per_image, const float* w_oihw, const float* bias,
+                              float* y_nhwc, int n, int h, int w, int relu) {
+    const int H = (h + 1) / 2, W = (w + 1) / 2;
+    if (h < 1 || w < 1 || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    HeadArgs a;
+    a.x = x_full; a.w = w_oihw; a.bias = bias; a.y = y_nhwc; a.n = n; a.cin = 5; a.H = H; a.W = W; a.relu = relu;
+    a.ffdnet = 1; a.src_h = h; a.src_w = w; a.sigma = sigma; a.sigma_stride = sigma_per_image ? 1 : 0;
     a.tiles_x = (W + CV_TX - 1) / CV_TX; a.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long tiles = (long long)n * a.tiles_x * a.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;

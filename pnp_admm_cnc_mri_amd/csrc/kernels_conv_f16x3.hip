@@ -443,6 +443,9 @@ __global__ __launch_bounds__(256) void k_conv_pack_w_h3(const float* w_oihw, _Fl
 struct TailH3Args {
     const float* x; const float* x2; const float* w; const float* bias; float* y;      // x2: null, or a tensor of x's shape added to it (the U-Net's last skip sum)
     int n, cout, H, W, tiles_x, tiles_y;
+    // FFDNet's output stage folded into the stores (models/network_ffdnet.py:70-73): cout = 4, and channel 2 dy + dx of pixel (y, x) is pixel
+    // (2 y + dy, 2 x + dx) of the ONE-channel full-resolution result y [n][1][out_h][out_w] (pixel shuffle + the crop of the padded row / column)
+    int shuffle, out_h, out_w;
 };
 __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t) {
     constexpr int HX = Geo<1>::HX;
@@ -512,17 +515,24 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gx = q.x0 + h3_row_pixel(4 * kb) + r;
-                if (gy < t.H && gx < t.W)
-                    t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+                const float v = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+                if (t.shuffle) {
+                    const int oy = 2 * gy + (i >> 1), ox = 2 * gx + (i & 1);
+                    if (gy < t.H && gx < t.W && oy < t.out_h && ox < t.out_w) t.y[((size_t)q.img * t.out_h + oy) * t.out_w + ox] = v;
+                } else if (gy < t.H && gx < t.W) {
+                    t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = v;
+                }
             }
         }
     }
 }
 
 hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
-                                     int n, int cout, int H, int W) {
+                                     int n, int cout, int H, int W, int shuffle_h, int shuffle_w) {
     if (cout < 1 || cout > 4 || (long long)H * W * CV_C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (shuffle_h && (cout != 4 || (shuffle_h + 1) / 2 != H || (shuffle_w + 1) / 2 != W)) return hipErrorInvalidValue;
     TailH3Args t;
+    t.shuffle = shuffle_h ? 1 : 0; t.out_h = shuffle_h; t.out_w = shuffle_w;
     t.x = x_nhwc; t.x2 = x2_nhwc; t.w = w_oihw; t.bias = bias; t.y = y_nchw; t.n = n; t.cout = cout; t.H = H; t.W = W;
     t.tiles_x = (W + CV_TX - 1) / CV_TX; t.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long tiles = (long long)n * t.tiles_x * t.tiles_y;

@@ -160,13 +160,15 @@ def _plain3x3(conv):
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros')
 
 
-def hip_stack_forward(seq, x, math='f32'):
+def hip_stack_forward(seq, x, math='f32', head=None, tail=None):
     """`seq(x)` for a [Conv3x3, ReLU] * (nb - 1) + Conv3x3 stack on libpnpmri.so's convolution kernels: 64 -> 64 layers on the
     fp32-MFMA implicit GEMM, a first layer with <= 8 input channels and a last layer with <= 4 output channels on the direct
     kernels -- DnCNN / FDnCNN / FFDNet then run without a MIOpen call.  Raises if the library or a GPU tensor is missing: no
     silent fallback to another device; layers the kernels do not cover (other channel counts, dilations) run in PyTorch
     inside the same call.  math='f16x3': the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores (float32-level
-    results, csrc/kernels_conv_f16x3.hip)."""
+    results, csrc/kernels_conv_f16x3.hip).
+    head / tail (FFDNet): callables that run the stack's first / last convolution themselves -- `head(conv, relu) -> nhwc tensor`
+    straight from the network's own input, `tail(conv, nhwc) -> result` straight into the network's own output."""
     import ctypes as C
     from . import _lib
     if not (x.is_cuda and x.dtype == torch.float32):
@@ -181,6 +183,12 @@ def hip_stack_forward(seq, x, math='f32'):
     while k < len(mods):
         m = mods[k]
         relu = k + 1 < len(mods) and isinstance(mods[k + 1], nn.ReLU)
+        if k == 0 and head is not None:
+            nhwc = head(m, relu)
+            k += 2 if relu else 1
+            continue
+        if tail is not None and nhwc is not None and not nhwc_split and k == len(mods) - 1:
+            return tail(m, nhwc)
         if nhwc is None and _plain3x3(m) and m.in_channels <= 8 and m.out_channels == 64:              # head
             hc = h.contiguous()
             n, _, H, W = hc.shape
@@ -278,16 +286,51 @@ class FFDNet(_PlainStack):
         super().__init__()
         self.model = _conv_stack(in_nc * 4 + 1, out_nc * 4, nc, nb)
 
-    def forward(self, x, sigma):
+    def _fused_ok(self, x, sigma):
+        """backend 'hip_f16x3', gray in and out, every layer on libpnpmri.so: the pad / pixel-unshuffle / concatenation in front of the stack
+        and the pixel-shuffle / crop behind it are folded into the first and last layer's kernels (pnp_ffdnet_head_nhwc, pnp_ffdnet_tail_f16x3)"""
+        convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
+        return (self.backend == 'hip_f16x3' and x.is_cuda and x.dtype == torch.float32 and x.shape[1] == 1 and hip_covers_stack(self.model)
+                and convs[0].in_channels == 5 and convs[-1].out_channels == 4 and sigma.numel() in (1, x.shape[0]))
+
+    def _forward_fused(self, x, sigma, out=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        xc = x.contiguous()
+        n, _, h, w = xc.shape
+        sg = sigma.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if out is None:
+            out = torch.empty_like(xc)
+        elif not (out.is_contiguous() and out.shape == xc.shape and out.dtype == torch.float32 and out.device == x.device):
+            raise ValueError('FFDNet: `out` must be a contiguous float32 tensor of the input\'s shape on its device')
+
+        def head(conv, relu):
+            y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, 64), dtype=torch.float32, device=x.device)
+            _lib.check(L.pnp_ffdnet_head_nhwc(stream, ptr(xc), ptr(sg), 1 if sg.numel() > 1 else 0, ptr(_hip_oihw(self.model, 0, conv)), ptr(conv.bias),
+                                              ptr(y), n, h, w, 1 if relu else 0))
+            return y
+
+        def tail(conv, nhwc):
+            _lib.check(L.pnp_ffdnet_tail_f16x3(stream, ptr(nhwc), ptr(_hip_oihw(self.model, len(self.model) - 1, conv)), ptr(conv.bias), ptr(out), n, h, w))
+            return out
+        return hip_stack_forward(self.model, xc, 'f16x3', head=head, tail=tail)
+
+    def forward(self, x, sigma, out=None):
         """sigma: [B,1,1,1] (or [1,1,1,1], broadcast over the batch -- the reference's
-        `sigma.repeat(1, 1, H/2, W/2)` only works for B = 1, models/network_ffdnet.py:67)."""
+        `sigma.repeat(1, 1, H/2, W/2)` only works for B = 1, models/network_ffdnet.py:67).  out: optional result tensor."""
+        if self._fused_ok(x, sigma):
+            return self._forward_fused(x, sigma, out)
         h, w = x.shape[-2:]
         x = F.pad(x, (0, int(math.ceil(w / 2) * 2 - w), 0, int(math.ceil(h / 2) * 2 - h)), mode='replicate')
         x = F.pixel_unshuffle(x, 2)
         m = sigma.to(x.dtype).expand(x.shape[0], 1, x.shape[-2], x.shape[-1])
         x = self._stack(torch.cat((x, m), 1))
         x = F.pixel_shuffle(x, 2)
-        return x[..., :h, :w]
+        x = x[..., :h, :w]
+        return x if out is None else out.copy_(x)
 
 
 def _hip_conv64(L, stream, x_nhwc, packed, bias, skip_nhwc, relu, dilation=1, math='f32', fmt=0):
@@ -783,7 +826,8 @@ class Denoiser:
             self.model.eval()
         self.former_idx = current_idx
 
-    def _one(self, x, i):
+    def _one(self, x, i, out=None):
+        """the model on one batch of at most cnn_batch slices; `out` (FFDNet): the result goes straight into this tensor"""
         fam = self.fam
         if fam == 'dncnn':
             return self.model(x)
@@ -808,7 +852,7 @@ class Denoiser:
                 x = augment_img_tensor4(x, 8 - i % 8 if i % 8 in (3, 5) else i % 8)
             return x
         sigma = torch.full((1, 1, 1, 1), self.noise_level_model / 255., dtype=x.dtype, device=x.device)
-        return self.model(x, sigma)
+        return self.model(x, sigma) if out is None else self.model(x, sigma, out=out)
 
     def _graph_ok(self, x):
         return (self.graph and x.is_cuda and x.shape[0] <= self.cnn_batch and self.cnn_dtype is None and not self.x8
@@ -863,7 +907,9 @@ class Denoiser:
         cd.benchmark = bool(find or before)
         try:
             for b0 in range(0, B, self.cnn_batch):
-                if self.cnn_dtype is None:
+                if self.cnn_dtype is None and self.fam == 'ffdnet' and isinstance(self.model, FFDNet) and out.is_contiguous():
+                    self._one(x[b0:b0 + self.cnn_batch], i, out=out[b0:b0 + self.cnn_batch])     # no copy: the last layer writes the slice itself
+                elif self.cnn_dtype is None:
                     out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)
                 else:
                     with torch.autocast('cuda', dtype=self.cnn_dtype):

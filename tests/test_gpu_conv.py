@@ -474,3 +474,42 @@ def test_conv_check_range_knob(env, monkeypatch):
     monkeypatch.setenv('PNP_CONV_CHECK_RANGE', '1')
     with pytest.raises(FloatingPointError):
         den(x, 0)
+
+
+@pytest.mark.parametrize('shape', [(2, 1, 64, 64), (3, 1, 31, 34), (1, 1, 17, 16), (5, 1, 128, 96)])
+def test_ffdnet_with_its_input_and_output_stages_inside_the_first_and_last_layer(env, shape):
+    """FFDNet under 'hip_f16x3': the replicate pad to even size, the pixel-unshuffle, the concatenation of the noise-level map
+    (models/network_ffdnet.py:58-68) are folded into the first layer's kernel (pnp_ffdnet_head_nhwc), the pixel-shuffle and the crop
+    (:70-73) into the last layer's (pnp_ffdnet_tail_f16x3), which writes into the caller's tensor: against the PyTorch forward with the
+    same weights (<= 1e-5), odd sizes, one noise level for the batch and one per image, no PyTorch convolution or copy involved."""
+    torch, D = env['torch'], env['D']
+    g = torch.Generator(device='cuda').manual_seed(sum(shape))
+    net, nlm, _ = D.build('ffdnet_gray')
+    net.load_state_dict(D.seeded_state_dict(net, 9))
+    net = net.eval().cuda()
+    x = torch.rand(*shape, device='cuda', generator=g)
+    for sigma in (torch.full((1, 1, 1, 1), 15 / 255., device='cuda'), torch.rand(shape[0], 1, 1, 1, device='cuda', generator=g) * 0.2):
+        net.backend = 'torch'
+        with torch.no_grad():
+            ref = net(x, sigma).clone()
+        net.backend = 'hip_f16x3'
+        assert net._fused_ok(x, sigma)
+        out = torch.full_like(x, float('nan'))
+        orig = torch.nn.Conv2d.forward
+
+        def boom(self, inp):
+            raise AssertionError('a PyTorch convolution was called')
+        torch.nn.Conv2d.forward = boom
+        try:
+            with torch.no_grad():
+                got = net(x, sigma, out=out)
+        finally:
+            torch.nn.Conv2d.forward = orig
+        assert got is out and bool(torch.isfinite(out).all())
+        assert _rel(out, ref) <= 1e-5, _rel(out, ref)
+    den = D.Denoiser('ffdnet_gray', net, nlm, backend='hip_f16x3', cnn_batch=2).to('cuda')      # batches beyond cnn_batch: slice by slice into `out`
+    net.backend = 'torch'
+    ref = D.Denoiser('ffdnet_gray', net, nlm, backend='torch', miopen_find=False).to('cuda')(x, 0).clone()
+    for m in [net]:
+        m.backend = 'hip_f16x3'
+    assert _rel(den(x, 0), ref) <= 1e-5
