@@ -907,7 +907,7 @@ class Denoiser:
         cd.benchmark = bool(find or before)
         try:
             for b0 in range(0, B, self.cnn_batch):
-                if self.cnn_dtype is None and self.fam == 'ffdnet' and isinstance(self.model, FFDNet) and out.is_contiguous():
+                if self.cnn_dtype is None and self.backend == 'hip_f16x3' and isinstance(self.model, FFDNet) and x.is_cuda and out.is_contiguous():
                     self._one(x[b0:b0 + self.cnn_batch], i, out=out[b0:b0 + self.cnn_batch])     # no copy: the last layer writes the slice itself
                 elif self.cnn_dtype is None:
                     out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)
