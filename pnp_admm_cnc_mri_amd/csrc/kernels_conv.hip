@@ -275,18 +275,29 @@ __global__ __launch_bounds__(256) void k_conv3x3_head(HeadArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     const float* xb = a.ffdnet ? a.x + (size_t)img * a.src_h * a.src_w : a.x + (size_t)img * a.cin * plane;
     const float sig = a.ffdnet ? a.sigma[(size_t)img * a.sigma_stride] : 0.f;
-    for (int e = tid; e < a.cin * CV_HY * CV_HX; e += 256) {
-        const int ci = e / (CV_HY * CV_HX), p = e - ci * (CV_HY * CV_HX), r = p / CV_HX, c = p - r * CV_HX;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        float v;
-        if (a.ffdnet) {
-            const int sy = min(2 * (in ? gy : 0) + (ci >> 1), a.src_h - 1), sx = min(2 * (in ? gx : 0) + (ci & 1), a.src_w - 1);
-            v = ci < 4 ? xb[(size_t)sy * a.src_w + sx] : sig;      // the convolution zero-pads the noise-level channel too
-        } else {
-            v = xb[(size_t)ci * plane + (size_t)(in ? gy : 0) * a.W + (in ? gx : 0)];
+    if (a.ffdnet) {
+        // the full-resolution patch, 2 CV_HY rows x 2 CV_HX columns, read row by row (consecutive threads, consecutive pixels) and
+        // de-interleaved into the four channel planes on the way into LDS
+        for (int e = tid; e < 4 * CV_HY * CV_HX; e += 256) {
+            const int pr = e / (2 * CV_HX), pc = e - pr * (2 * CV_HX), r = pr >> 1, c = pc >> 1, ci = 2 * (pr & 1) + (pc & 1);
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int sy = min(2 * (in ? gy : 0) + (pr & 1), a.src_h - 1), sx = min(2 * (in ? gx : 0) + (pc & 1), a.src_w - 1);
+            const float v = xb[(size_t)sy * a.src_w + sx];
+            xin[(ci * CV_HY + r) * CV_HX + c] = in ? v : 0.f;
         }
-        xin[e] = in ? v : 0.f;
+        for (int p = tid; p < CV_HY * CV_HX; p += 256) {           // the convolution zero-pads the noise-level channel too
+            const int r = p / CV_HX, c = p - r * CV_HX, gy = y0 - 1 + r, gx = x0 - 1 + c;
+            xin[4 * CV_HY * CV_HX + p] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? sig : 0.f;
+        }
+    } else {
+        for (int e = tid; e < a.cin * CV_HY * CV_HX; e += 256) {
+            const int ci = e / (CV_HY * CV_HX), p = e - ci * (CV_HY * CV_HX), r = p / CV_HX, c = p - r * CV_HX;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const float v = xb[(size_t)ci * plane + (size_t)(in ? gy : 0) * a.W + (in ? gx : 0)];
+            xin[e] = in ? v : 0.f;
+        }
     }
     for (int e = tid; e < a.cin * 9 * CV_C; e += 256) {            // w_oihw [64][cin][3][3] -> [ci * 9 + tap][out]
         const int out = e & 63, k = e >> 6;                        // k = ci * 9 + tap

@@ -506,8 +506,28 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
         }
     }
     // accumulator (reg r, lane (i, kb)) of M tile mt = pixel (tile row 2 w + mt, column h3_row_pixel(4 kb + r)), output channel i
+    const float b = (col && t.bias) ? t.bias[i] : 0.f;
+    if (t.shuffle) {
+        // FFDNet: the tile's 8 x 16 x 4 values are a 16 x 32 block of the full-resolution result; it is assembled in LDS (the input tile is
+        // no longer needed once every wave is past its taps) and leaves as whole rows, two consecutive pixels per thread
+        __syncthreads();
+        if (col) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xin[(2 * (2 * wv + mt) + (i >> 1)) * 32 + 2 * (h3_row_pixel(4 * kb) + r) + (i & 1)] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+        }
+        __syncthreads();
+        const int orow = tid >> 4, ocol = 2 * (tid & 15), oy = 2 * q.y0 + orow, ox = 2 * q.x0 + ocol;
+        if (oy < t.out_h) {
+            float* dst = t.y + ((size_t)q.img * t.out_h + oy) * t.out_w + ox;
+            if (ox < t.out_w) dst[0] = xin[orow * 32 + ocol];
+            if (ox + 1 < t.out_w) dst[1] = xin[orow * 32 + ocol + 1];
+        }
+        return;
+    }
     if (col) {
-        const float b = t.bias ? t.bias[i] : 0.f;
         const size_t plane = (size_t)t.H * t.W;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -515,13 +535,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gx = q.x0 + h3_row_pixel(4 * kb) + r;
-                const float v = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
-                if (t.shuffle) {
-                    const int oy = 2 * gy + (i >> 1), ox = 2 * gx + (i & 1);
-                    if (gy < t.H && gx < t.W && oy < t.out_h && ox < t.out_w) t.y[((size_t)q.img * t.out_h + oy) * t.out_w + ox] = v;
-                } else if (gy < t.H && gx < t.W) {
-                    t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = v;
-                }
+                if (gy < t.H && gx < t.W)
+                    t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
             }
         }
     }
