@@ -593,3 +593,27 @@ def test_bench_line_at_512_with_its_cpu_legs():
     assert '512x512' in j['metric'] and j['config']['path'] == 'fused' and j['f64'] is None
     assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5 and j['parity']['iterations'] == 3
     assert j['cpu_baseline']['value'] > 0 and j['cpu_baseline_all_cores'].get('value', 0) > 0
+
+
+def test_example_driver_runs_the_pnp_mains_like_the_reference(golden_inputs, tmp_path):
+    """examples/run_reference_defaults.py in its PnP form = what `python "【6】PNP_ADMM_CNC_D .py"` does (S6:569-620): a reference-shaped tree
+    (CS_MRI/*.mat, testsets/Set1/05.png, model_zoo/<model>.pth with KAIR keys), the committed preset, the authors' log line -- here with the
+    contractive fixture weights, whose 50-iteration result the unmodified script produced too (tests/golden/pnp50_set1_05.npz)."""
+    import torch
+    from conftest import weights50
+    ts, res = _testset(tmp_path, golden_inputs['gray'])
+    os.symlink(os.path.join(GOLD, 'cs_mri_fixture'), tmp_path / 'CS_MRI')
+    (tmp_path / 'model_zoo').mkdir()
+    torch.save(weights50('ffdnet_gray'), tmp_path / 'model_zoo' / 'ffdnet_gray.pth')
+    env_ = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'run_reference_defaults.py'), '--root', str(tmp_path), '--solver', 'pnp_cnc',
+                        '--model', 'ffdnet_gray', '--cnn-backend', 'hip_f16x3', '--results', str(res)], env=env_, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = r.stdout.decode()
+    known = json.load(open(os.path.join(GOLD, 'pnp_known.json')))['known50']['cnc_d_ffdnet_gray']           # '05.png - PSNR: 16.3045 dB; ...'
+    want = float(known.split('PSNR:')[1].split('dB')[0])
+    got = float([l for l in out.splitlines() if l.startswith('psnr')][0].split("'")[1])
+    assert abs(got - want) <= 0.01, (got, known)
+    log = (res / 'Set1_dn_ffdnet_gray' / 'Set1_dn_ffdnet_gray.log').read_text()
+    assert 'PSNR: %.4f dB' % got in log and '05PNP_ADMM_CNC_D.png' in os.listdir(res / 'Set1_dn_ffdnet_gray')
