@@ -351,3 +351,25 @@ def test_drunet_fifty_iterations_on_the_miopen_backends_in_a_fresh_process():
         assert e['rel_l2'] <= 1e-5, e
         assert abs(e['psnr'] - e['psnr_golden']) <= 0.01, e
         assert abs(e['psnr'] - float(e['log_line'].split('PSNR:')[1].split('dB')[0])) <= 0.01, e
+
+
+@pytest.mark.parametrize('name,backend,tags', [('ffdnet_gray', 'hip_f16x3', ('cnc_d_ffdnet_gray', 'cnc_d_ffdnet_gray_radial30')),
+                                               ('ffdnet_gray', 'torch', ('cnc_d_ffdnet_gray', 'cnc_d_ffdnet_gray_radial30')),
+                                               ('drunet_gray', 'hip_f16x3', ('cnc_d_drunet_gray', 'cnc_d_drunet_gray_cartesian30'))])
+def test_batched_pnp_with_a_mask_bank_at_fifty_iterations(env50, golden_inputs, name, backend, tags, tmp_path):
+    """The build's extension of the reference loop -- many slices per call, a mask per slice -- at the reference's own run length: six
+    copies of the reference's image with masks alternating between the two for which the unmodified script produced a 50-iteration golden;
+    every slice of the ONE batched call must be its mask's golden (1e-5), whatever its neighbours in the batch are."""
+    from conftest import weights50
+    mk = {'cnc_d_ffdnet_gray': 'Q_Random30', 'cnc_d_ffdnet_gray_radial30': 'Q_Radial30', 'cnc_d_drunet_gray': 'Q_Random30',
+          'cnc_d_drunet_gray_cartesian30': 'Q_Cartesian30'}
+    masks = np.stack([golden_inputs['masks'][mk[t]] for t in tags]).astype(np.uint8)
+    mid = np.array([0, 1, 0, 1, 1, 0], np.int32)
+    opts = dict(env50['known50'][tags[0] + '_opts'])
+    opts['iter_num'] = int(opts['iter_num'])
+    assert opts['iter_num'] == 50
+    out, _ = env50['S'].PNP_ADMM_CNC_D(name, masks, golden_inputs['noises'], images=np.repeat(golden_inputs['gray'][None], len(mid), axis=0), mask_id=mid,
+                                       model=weights50(name), results=str(tmp_path), cnn_backend=backend, **opts)
+    for b, k in enumerate(mid):
+        err = rel_l2(out[b], env50['gold50'][tags[k]])
+        assert err <= 1e-5, (b, tags[k], err)
