@@ -203,6 +203,88 @@ def fifty():
     print(json.dumps(known, indent=1, sort_keys=True))
 
 
+def trained():
+    """Round 5: 50-iteration goldens of the unmodified S6 / S3 with a TRAINED FFDNet (oracle/train_fixture_denoiser.py ->
+    tests/golden/ffdnet_gray_trained.npz): PNP_ADMM_CNC_D on Q_Random30 and Q_Radial30 (BASELINE.json configs[2]'s pair), PNP_ADMM_L1_D on
+    Q_Random30, at the committed presets.  The scripts' mains are run with --iter_num 1 on the contractive fixture weights only to obtain
+    their solver functions, masks and option dicts; the calls of record pass iter_num = 50 themselves."""
+    import contractive as CT
+    MG.install_shims()
+    if not hasattr(np, 'int'):
+        np.int = int
+    d = MG.scratch_dir()
+    os.chdir(d)
+    os.makedirs('model_zoo')
+    torch.set_num_threads(8)
+    kj = os.path.join(MG.GOLD, 'pnp_known.json')
+    meta = json.load(open(kj))
+    for n in ('drunet_gray', 'dncnn_25', 'dncnn_15'):               # what the mains load
+        net, _, _ = D.build(n)
+        torch.save(D.contractive_state_dict(net, D.family(n), meta['known50']['seeds'][n], meta['gains50'][n]), os.path.join('model_zoo', n + '.pth'))
+    w = np.load(os.path.join(MG.GOLD, 'ffdnet_gray_trained.npz'))
+    net, _, _ = D.build('ffdnet_gray')
+    sd = {k: torch.from_numpy(w[k]) for k in net.state_dict()}
+    net.load_state_dict(sd, strict=True)
+    torch.save(sd, os.path.join('model_zoo', 'ffdnet_gray.pth'))
+    npz = os.path.join(MG.GOLD, 'pnp50_set1_05.npz')
+    arrays = dict(np.load(npz))
+    known = meta['known50']
+
+    def line(lines):
+        return [l for l in lines if 'PSNR' in l and '05.png' in l][-1]
+
+    g, _, _ = MG.run_script(S6, ['--iter_num', '1'], 'Set1_dn_drunet_gray')
+    for k, tag in ((0, 'trained_cnc_d_ffdnet_gray'), (1, 'trained_cnc_d_ffdnet_gray_radial30')):
+        opts = dict(g['PNP_ADMM_CNC_D_opts2'], iter_num=50)
+        cap = MG._Capture('Set1_dn_ffdnet_gray')
+        with contextlib.redirect_stdout(io.StringIO()):
+            o, _ = g['PNP_ADMM_CNC_D']('ffdnet_gray', g['mask'][k], g['noises'], **opts)
+        arrays[tag] = np.asarray(o[0], np.float32)
+        known[tag] = line(cap.lines)
+        known[tag + '_opts'] = {kk: float(v) for kk, v in opts.items()}
+        known[tag + '_sum'] = float(arrays[tag].astype(np.float64).sum())
+        print(tag, known[tag], flush=True)
+    # the same run cut short: a trained denoiser is locally EXPANSIVE (Lipschitz constant ~2 at the starting point, recorded below), any
+    # two float32 implementations drift apart with the iteration count -- these are the counts at which 1e-5 can still be asked for
+    for n_it in (2, 5, 10, 20):
+        opts = dict(g['PNP_ADMM_CNC_D_opts2'], iter_num=n_it)
+        with contextlib.redirect_stdout(io.StringIO()):
+            o, _ = g['PNP_ADMM_CNC_D']('ffdnet_gray', g['mask'][0], g['noises'], **opts)
+        tag = 'trained_cnc_d_ffdnet_gray_it%d' % n_it
+        arrays[tag] = np.asarray(o[0], np.float32)
+        known[tag + '_opts'] = {kk: float(v) for kk, v in opts.items()}
+        known[tag + '_sum'] = float(arrays[tag].astype(np.float64).sum())
+    g, _, _ = MG.run_script(S3, ['--iter_num', '1'], 'Set1_dn_drunet_gray')
+    opts = dict(g['PNP_ADMM_L1_D_opts3'], iter_num=50)
+    cap = MG._Capture('Set1_dn_ffdnet_gray')
+    with contextlib.redirect_stdout(io.StringIO()):
+        o = g['PNP_ADMM_L1_D']('ffdnet_gray', g['mask'][0], g['noises'], **opts)
+    tag = 'trained_l1_d_ffdnet_gray'
+    arrays[tag] = np.asarray(o[0], np.float32)
+    known[tag] = line(cap.lines)
+    known[tag + '_opts'] = {kk: float(v) for kk, v in opts.items()}
+    known[tag + '_sum'] = float(arrays[tag].astype(np.float64).sum())
+    print(tag, known[tag], flush=True)
+    # the local Lipschitz constant of the trained denoiser at the loop's starting point (recorded, not asserted)
+    gold_in = np.load(os.path.join(MG.GOLD, 'inputs_set1_05.npz'))
+    net.eval()
+    for p_ in net.parameters():
+        p_.requires_grad = False
+    den = D.Denoiser('ffdnet_gray', net, 15)
+    mask0 = np.unpackbits(gold_in['Q_Random30_packbits'])[:65536].reshape(256, 256).astype(np.float64)
+    y0 = np.fft.fft2(np.float32(gold_in['gray_u8'] / 255.)) * mask0 + gold_in['noises_c128'] * 3.0
+    x0 = torch.from_numpy(np.abs(np.fft.ifft2(y0)).astype(np.float32))[None, None]
+    meta.setdefault('trained', {})['lipschitz_at_x0'] = CT.lipschitz_at(lambda t: den._one(t, 0), x0, iters=12)
+    tj = os.path.join(ROOT, 'gpurun_out', 'ffdnet_gray_trained.json')
+    if os.path.exists(tj):
+        meta['trained']['training'] = json.load(open(tj))
+    meta['trained']['weights'] = 'tests/golden/ffdnet_gray_trained.npz (oracle/train_fixture_denoiser.py)'
+    np.savez_compressed(npz, **arrays)
+    with open(kj, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta['trained'], indent=1, sort_keys=True))
+
+
 def MG_sigmas(nlm, iters):
     from pnp_admm_cnc_mri_amd import utils_pnp
     return utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1]
@@ -213,6 +295,8 @@ def main():
         return extra()
     if '--fifty' in sys.argv:
         return fifty()
+    if '--trained' in sys.argv:
+        return trained()
     MG.install_shims()
     d = MG.scratch_dir()
     os.chdir(d)

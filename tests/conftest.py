@@ -70,3 +70,12 @@ def weights50(name):
     if fam == 'ircnn':
         return {str(i): D.contractive_state_dict(net, fam, seed + i, gains['%s/%d' % (name, i)]) for i in range(25)}
     return D.contractive_state_dict(net, fam, seed, gains[name])
+
+
+def weights_trained(name='ffdnet_gray'):
+    """The TRAINED fixture network (oracle/train_fixture_denoiser.py: FFDNet-gray trained KAIR-style on seeded synthetic images for a few
+    minutes; tests/golden/ffdnet_gray_trained.npz) as a state_dict -- the weights behind the 'trained_*' goldens of pnp50_set1_05.npz."""
+    import torch
+    assert name == 'ffdnet_gray'
+    w = np.load(os.path.join(GOLD, 'ffdnet_gray_trained.npz'))
+    return {k: torch.from_numpy(w[k]) for k in w.files}

@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
-from conftest import weights50, GOLD
+from conftest import weights50, weights_trained, GOLD
 from pnp_admm_cnc_mri_amd import solvers_pnp as S
 from oracle import admm_oracle as O
 args = sys.argv[1:]
@@ -38,6 +38,13 @@ for tag in sorted(gold.files):
         if tag == 'cnc_dncnn_pair':
             o = {k: (int(v) if k == 'iter_num' else v) for k, v in known[tag + '_opts'].items()}
             out, _ = S.PNP_ADMM_CNC_DnCNN('dncnn_25', 'dncnn_15', masks['Q_Random30'], noises, model=weights50('dncnn_25'), **kw, **o)
+        elif tag.startswith('trained_'):
+            name = 'ffdnet_gray'
+            o = {k: (int(v) if k == 'iter_num' else v) for k, v in known[tag + '_opts'].items()}
+            if 'l1_d' in tag:
+                out = S.PNP_ADMM_L1_D(name, masks['Q_Random30'], noises, model=weights_trained(), **kw, **o)
+            else:
+                out, _ = S.PNP_ADMM_CNC_D(name, masks['Q_Radial30' if tag.endswith('radial30') else 'Q_Random30'], noises, model=weights_trained(), **kw, **o)
         elif tag.startswith('cnc_d_'):
             parts = tag[6:].split('_'); name = '_'.join(parts[:2])
             m = masks[{'radial30': 'Q_Radial30', 'cartesian30': 'Q_Cartesian30'}.get(parts[-1], 'Q_Random30')]

@@ -259,3 +259,46 @@ def test_oracle_pnp_loops_at_fifty_iterations_vs_the_unmodified_reference(golden
         assert den.former_idx == 7                                   # the bank was walked down from model 24 to model 7 (sigma 49 -> 15)
     psnr = O.calculate_psnr(np.round(x.astype(np.float64) * 255.), golden_inputs['gray'])
     assert ('PSNR: %.4f dB' % psnr if loop == 'cnc' else 'PSNR: %.2f dB' % psnr) in line, (psnr, line)
+
+
+def test_trained_fixture_network_loads_strictly_and_denoises():
+    """tests/golden/ffdnet_gray_trained.npz (oracle/train_fixture_denoiser.py): KAIR's FFDNet keys and shapes, finite weights well inside
+    the half range, and a network that does what its training record says -- on a seeded image with sigma = 25 noise it gains several dB."""
+    from conftest import weights_trained
+    from pnp_admm_cnc_mri_amd import synthetic as S
+    sd = weights_trained()
+    net, _, _ = D.build('ffdnet_gray')
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    assert all(bool(torch.isfinite(v).all()) and float(v.abs().max()) < 10 for v in sd.values())
+    rec = json.load(open(os.path.join(GOLD, 'pnp_known.json')))['trained']
+    assert rec['training']['held_out_psnr']['25']['denoised'] - rec['training']['held_out_psnr']['25']['noisy'] > 8 and rec['lipschitz_at_x0'] > 1
+    clean = torch.from_numpy(S.phantom(7))[None, None]
+    noisy = clean + (25 / 255.) * torch.from_numpy(np.random.default_rng(1).standard_normal(clean.shape).astype(np.float32))
+    with torch.no_grad():
+        den = net(noisy, torch.full((1, 1, 1, 1), 25 / 255.))
+    mse = lambda a: float(((a - clean) ** 2).mean())
+    assert 10 * np.log10(mse(noisy) / mse(den)) > 6
+
+
+@pytest.mark.parametrize('n_it', [5, 20])
+def test_oracle_pnp_loop_with_the_trained_network_vs_the_unmodified_reference(golden_inputs, n_it):
+    """the oracle's PNP_ADMM_CNC_D loop driven by the TRAINED FFDNet on the CPU against the unmodified S6's output with the same weights
+    (tests/golden/pnp50_set1_05.npz: trained_cnc_d_ffdnet_gray_it<n>): same CPU convolutions, same NumPy transforms -> float32 round-off"""
+    from conftest import rel_l2, weights_trained
+    from oracle import admm_oracle as O
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    meta = json.load(open(os.path.join(GOLD, 'pnp_known.json')))['known50']
+    gold = np.load(os.path.join(GOLD, 'pnp50_set1_05.npz'))
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    y = O.synthesize(np.float32(golden_inputs['gray'] / 255.), mask, golden_inputs['noises'])
+    net, nlm, _ = D.build('ffdnet_gray')
+    net.load_state_dict(weights_trained())
+    den = D.Denoiser('ffdnet_gray', net.eval(), nlm)
+
+    def denoise(a, i):
+        with torch.no_grad():
+            return den._one(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None], i)[0, 0].numpy()
+    o = meta['trained_cnc_d_ffdnet_gray_it%d_opts' % n_it]
+    x = O.pnp_admm_cnc(y, mask, denoise, n_it, o['alpha'], o['lambda1'], o['reo'], o['b'])
+    assert rel_l2(x, gold['trained_cnc_d_ffdnet_gray_it%d' % n_it]) <= 2e-6, rel_l2(x, gold['trained_cnc_d_ffdnet_gray_it%d' % n_it])

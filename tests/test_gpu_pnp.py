@@ -373,3 +373,51 @@ def test_batched_pnp_with_a_mask_bank_at_fifty_iterations(env50, golden_inputs, 
     for b, k in enumerate(mid):
         err = rel_l2(out[b], env50['gold50'][tags[k]])
         assert err <= 1e-5, (b, tags[k], err)
+
+
+# ----------------------------------------------------------------------------------------------
+# A TRAINED denoiser (oracle/train_fixture_denoiser.py: the reference's FFDNet architecture trained KAIR-style for a few minutes on seeded
+# synthetic images; +9.5 / +11.9 / +15.4 dB on held-out images at sigma 15 / 25 / 50; tests/golden/ffdnet_gray_trained.npz) under the
+# unmodified S6 / S3 at the committed presets.  With it PNP_ADMM_CNC_D reaches 28.76 dB after 5 iterations (ADMM_CNC: 24.58 dB after
+# 50) -- and, like every trained denoiser, it is locally EXPANSIVE (Lipschitz constant 1.95 at the starting point): past ~10 iterations
+# any two float32 implementations of the loop drift apart, the reference's CPU-PyTorch run and PyTorch-ROCm / MIOpen included.
+# So: 1e-5 where float32 can hold it (2, 5, 10 iterations; measured 3e-7 .. 8e-7 on all three backends), 1e-4 at 20 (1.8e-5 .. 3.2e-5),
+# and at the presets' own 50 the PSNR of the authors' log line to 0.01 dB with the images 1e-3 .. 1e-2 apart -- the same band for
+# MIOpen, the fp32-MFMA kernels and the split-half f16 kernels.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('n_it,tol', [(2, 1e-5), (5, 1e-5), (10, 1e-5), (20, 1e-4)])
+def test_pnp_with_a_trained_ffdnet_where_float32_can_hold_the_bar(env50, golden_inputs, backend, n_it, tol, tmp_path, monkeypatch):
+    from conftest import weights_trained
+    tag = 'trained_cnc_d_ffdnet_gray_it%d' % n_it
+    opts = dict(env50['known50'][tag + '_opts'])
+    opts['iter_num'] = int(opts['iter_num'])
+    assert opts['iter_num'] == n_it
+    if backend == 'hip_f16x3' and n_it == 5:
+        monkeypatch.setenv('PNP_CONV_CHECK_RANGE', '1')             # every activation of the trained network stays inside the half range
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    out, _ = env50['S'].PNP_ADMM_CNC_D('ffdnet_gray', mask, golden_inputs['noises'], images=golden_inputs['gray'][None], model=weights_trained(),
+                                       results=str(tmp_path), cnn_backend=backend, **opts)
+    ref = env50['gold50'][tag]
+    assert rel_l2(out[0], ref) <= tol, rel_l2(out[0], ref)
+    assert _psnr_close(out[0], ref, golden_inputs['gray'])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('tag', ['trained_cnc_d_ffdnet_gray', 'trained_cnc_d_ffdnet_gray_radial30', 'trained_l1_d_ffdnet_gray'])
+def test_pnp_with_a_trained_ffdnet_at_the_presets_fifty_iterations(env50, golden_inputs, tag, backend, tmp_path):
+    from conftest import weights_trained
+    opts = dict(env50['known50'][tag + '_opts'])
+    opts['iter_num'] = int(opts['iter_num'])
+    assert opts['iter_num'] == 50
+    mask = golden_inputs['masks']['Q_Radial30' if tag.endswith('radial30') else 'Q_Random30'].astype(np.float64)
+    kw = dict(images=golden_inputs['gray'][None], model=weights_trained(), results=str(tmp_path), cnn_backend=backend)
+    if 'l1_d' in tag:
+        out = env50['S'].PNP_ADMM_L1_D('ffdnet_gray', mask, golden_inputs['noises'], **kw, **opts)
+    else:
+        out, _ = env50['S'].PNP_ADMM_CNC_D('ffdnet_gray', mask, golden_inputs['noises'], **kw, **opts)
+    ref = env50['gold50'][tag]
+    assert np.isfinite(out[0]).all()
+    assert rel_l2(out[0], ref) <= 3e-2, rel_l2(out[0], ref)          # measured 7e-4 .. 1e-2, all three backends alike (the loop is expansive by now)
+    psnr = O.calculate_psnr(np.round(out[0].astype(np.float64) * 255), golden_inputs['gray'])
+    assert abs(psnr - float(env50['known50'][tag].split('PSNR:')[1].split('dB')[0])) <= 0.01, (psnr, env50['known50'][tag])
