@@ -40,6 +40,12 @@ def fixture_weights(model_name, net, kind):
     from pnp_admm_cnc_mri_amd import denoisers as D
     if kind == 'he':
         return D.seeded_state_dict(net, 1), None
+    if kind == 'trained':                               # FFDNet-gray only: the network trained by oracle/train_fixture_denoiser.py
+        import torch
+        if model_name != 'ffdnet_gray':
+            raise SystemExit("--weights trained: only ffdnet_gray has a trained fixture (tests/golden/ffdnet_gray_trained.npz)")
+        w = np.load(os.path.join(ROOT, 'tests', 'golden', 'ffdnet_gray_trained.npz'))
+        return {k: torch.from_numpy(w[k]) for k in w.files}, None
     meta = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'pnp_known.json')))
     seed, gains, fam = meta['known50']['seeds'][model_name], meta['gains50'], D.family(model_name)
     if fam == 'ircnn':
@@ -66,9 +72,10 @@ def main():
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True for the whole run')
     ap.add_argument('--launch-timeout', type=float, default=float(os.environ.get('PNP_BENCH_TIMEOUT', 1500)))
     ap.add_argument('--rehearse-gloo', action='store_true', help='N > 1 on a box with ONE GPU: gloo backend, all ranks on cuda:0')
-    ap.add_argument('--weights', default='contractive', choices=['contractive', 'he'],
-                    help="seeded synthetic weights: 'contractive' (the 50-iteration goldens' fixture weights: a stable loop, a meaningful "
-                         "parity record) or 'he' (He-scaled random weights: the lines of rounds 2-4)")
+    ap.add_argument('--weights', default='auto', choices=['auto', 'contractive', 'he', 'trained'],
+                    help="'auto' (default): 'trained' where a trained fixture exists (ffdnet_gray), 'contractive' otherwise.  'contractive' (the 50-iteration goldens' fixture weights: a stable loop, a meaningful "
+                         "parity record), 'he' (He-scaled random weights: the lines of rounds 2-4) or 'trained' (ffdnet_gray: the network trained by "
+                         "oracle/train_fixture_denoiser.py -- a working denoiser's activation statistics)")
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle loop on three slices (N = 1 only; a few CPU seconds)')
     args = ap.parse_args()
 
@@ -97,6 +104,8 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     fam = D.family(args.model)
+    if args.weights == 'auto':          # a working denoiser's activation statistics where the repo has one (they set the clock the f16x3 kernel holds)
+        args.weights = 'trained' if args.model == 'ffdnet_gray' else 'contractive'
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     H = W = args.size
     B = args.batch

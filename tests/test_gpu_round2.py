@@ -553,7 +553,7 @@ def test_bench_pnp_line_and_its_two_rank_launch():
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][0])
     assert j['n_gpus'] == 1 and j['gather_ms'] is None and j['x_finite'] and j['denoiser_outputs_finite']
-    assert j['config']['weights'] == 'contractive' and j['parity']['iterations'] == 3 and j['parity']['slices'] == [0, 7, 15]
+    assert j['config']['weights'] == 'trained' and j['parity']['iterations'] == 3 and j['parity']['slices'] == [0, 7, 15]      # ffdnet_gray: the trained fixture network
     assert max(j['parity']['rel_l2_vs_oracle']) <= 1e-5, j['parity']
     assert abs(j['denoiser']['flop_per_call_per_slice'] / 1e9 - 15.9) <= 0.4
     assert j['denoiser']['roofline']['bound'] == 'mfma_f32' and 0 < j['denoiser']['roofline']['frac'] < 1
