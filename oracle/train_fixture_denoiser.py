@@ -61,17 +61,28 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--patch', type=int, default=96)
     ap.add_argument('--seed', type=int, default=20261005)
-    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'ffdnet_gray_trained.npz'))
+    ap.add_argument('--model', default='ffdnet_gray', choices=['ffdnet_gray', 'drunet_gray'],
+                    help='drunet_gray: for profiles/experiments/drunet_trained_check.py only (32 M parameters: nothing is committed)')
+    ap.add_argument('--out', default=None)
     a = ap.parse_args()
+    if a.out is None:
+        a.out = os.path.join(ROOT, 'gpurun_out', a.model + '_trained.npz')
     dev = torch.device('cuda', 0)
     torch.manual_seed(a.seed)
     t0 = time.time()
     train = torch.from_numpy(images(192, 1)).to(dev)
     held = torch.from_numpy(images(16, 2)).to(dev)
     print('images: %.1f s' % (time.time() - t0), flush=True)
-    net, _, _ = D.build('ffdnet_gray')
+    net, _, _ = D.build(a.model)
     net = net.to(dev).train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    drunet = a.model == 'drunet_gray'
+
+    def run(noisy, sigma):
+        """FFDNet takes the level as its second argument; DRUNet as a second input channel (S6:36-38)"""
+        if drunet:
+            return net(torch.cat((noisy, sigma.expand(-1, 1, noisy.shape[2], noisy.shape[3])), 1))
+        return net(noisy, sigma)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4 if a.model == 'drunet_gray' else 1e-3)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, a.steps, eta_min=2e-5)
     g = torch.Generator(device=dev).manual_seed(a.seed)
     torch.backends.cudnn.benchmark = True
@@ -87,7 +98,7 @@ def main():
             clean = clean.transpose(2, 3)
         sigma = torch.rand((a.batch, 1, 1, 1), device=dev, generator=g) * (75.0 / 255.0)
         noisy = clean + sigma * torch.randn(clean.shape, device=dev, generator=g)
-        loss = torch.nn.functional.l1_loss(net(noisy, sigma), clean)
+        loss = torch.nn.functional.l1_loss(run(noisy, sigma), clean)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -101,7 +112,7 @@ def main():
         for s in (15, 25, 50):
             sig = torch.full((held.shape[0], 1, 1, 1), s / 255.0, device=dev)
             noisy = held[:, None] + sig * torch.randn(held[:, None].shape, device=dev, generator=g)
-            den = net(noisy, sig)
+            den = run(noisy, sig)
             rec['held_out_psnr'][str(s)] = {'noisy': psnr(noisy, held[:, None]), 'denoised': psnr(den, held[:, None])}
             print('sigma %d: noisy %.2f dB -> denoised %.2f dB' % (s, rec['held_out_psnr'][str(s)]['noisy'], rec['held_out_psnr'][str(s)]['denoised']), flush=True)
     sd = {k: v.detach().float().cpu().numpy() for k, v in net.state_dict().items()}
