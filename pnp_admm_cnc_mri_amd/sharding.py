@@ -81,7 +81,9 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
     Every rank passes the SAME full `images` / `y` / `mask_id`; returns an array [B_total, H, W] on `dst`
     (float32; float64 when the solver is run with precision='f64'), None elsewhere.  With no process
     group it is a plain call.
-    gather_device: torch device for the collective (default: cuda:<local device> under nccl, cpu under gloo).
+    gather_device: torch device for the collective (default under nccl: the device the solver's result lies on -- see
+    collective_device; cpu under gloo).  Solver contract: called as solver(mask, noises, images=/y=/mask_id= slices, **opts,
+    return_device=True when its signature takes that keyword) and returns a [b,H,W] tensor or the reference's list (+ extras in a tuple).
     """
     import torch
     import torch.distributed as dist
@@ -89,11 +91,11 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
     if src is None:
         raise ValueError('solve_sharded needs images= or y= (file-based inputs cannot be sharded by index)')
     B_total = len(src)
-    if not (dist.is_available() and dist.is_initialized()):
-        lo, hi, world = 0, B_total, 1
+    grouped = dist.is_available() and dist.is_initialized()
+    if not grouped:
+        lo, hi = 0, B_total
     else:
-        world = dist.get_world_size(group)
-        lo, hi = shard_range(B_total, world, dist.get_rank(group))
+        lo, hi = shard_range(B_total, dist.get_world_size(group), dist.get_rank(group))
     kw = dict(solver_kwargs)
     real = np.float64 if kw.get('precision') == 'f64' else np.float32
     if images is not None:
@@ -109,7 +111,9 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
     # copy of the job is the root's, of the gathered result (config 4: 128 MiB per rank stay off PCIe in both directions).
     tdt = torch.float64 if real is np.float64 else torch.float32
     if hi > lo:
-        res = solver(mask, noises, return_device=True, **kw)
+        # solver contract: `return_device=True` -> ONE [b,H,W] tensor (every entry point of this package); a solver whose signature has
+        # neither that keyword nor **opts is called without it and may return the reference's list of host arrays
+        res = solver(mask, noises, **(dict(kw, return_device=True) if _accepts(solver, 'return_device') else kw))
         out = res[0] if isinstance(res, tuple) else res
         if torch.is_tensor(out):
             x_local = out
@@ -117,12 +121,38 @@ def solve_sharded(solver, mask, noises, images=None, y=None, mask_id=None, dst=0
             x_local = torch.from_numpy(np.stack([np.asarray(out[n], dtype=real) for n in range(hi - lo)]))
         if tuple(x_local.shape[:1]) != (hi - lo,):
             raise TypeError('solve_sharded: the solver returned %s for a shard of %d slices' % (tuple(x_local.shape), hi - lo))
+        if x_local.dtype != tdt:                          # one dtype on every rank (empty shards send zeros of `tdt`): mixed dtypes hang a gather
+            x_local = x_local.to(tdt)
     else:
         m = np.asarray(mask)
         x_local = torch.zeros((0,) + tuple(m.shape[-2:]), dtype=tdt)
-    if world == 1:
+    if not grouped:
         return x_local.cpu().numpy()
-    if gather_device is None:
-        gather_device = torch.device('cuda', kw.get('device', 0)) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    if gather_device is None:                             # (a one-rank group still runs the collective: RCCL's first contact is a test)
+        gather_device = collective_device(x_local, dist.get_backend(group), kw.get('device'))
     x_all = gather_slices(x_local.to(gather_device), B_total, dst=dst, group=group)     # .to(): a no-op for a tensor already there
     return None if x_all is None else x_all.cpu().numpy()
+
+
+def collective_device(x_local, backend, device=None):
+    """Where the final gather runs.  gloo: the CPU.  nccl (= RCCL): the card the shard's result already lies on -- the solver may have
+    been bound to its device with functools.partial (then `device` never reaches solve_sharded's keywords), and RCCL must be handed
+    a tensor on THIS rank's GPU, never a copy onto the root's.  A CPU tensor (an empty shard, a list-returning solver) goes to the
+    explicit device=, else to the process's LOCAL_RANK (solvers.resolve_device)."""
+    import torch
+    if backend != 'nccl':
+        return torch.device('cpu')
+    if x_local.is_cuda:
+        return x_local.device
+    from .solvers import resolve_device
+    return torch.device('cuda', resolve_device(device))
+
+
+def _accepts(fn, name):
+    """does `fn` (possibly a functools.partial) take the keyword `name`, by name or through **kwargs?"""
+    import inspect
+    try:
+        ps = inspect.signature(fn).parameters.values()
+    except (TypeError, ValueError):
+        return True
+    return any(p.name == name or p.kind is inspect.Parameter.VAR_KEYWORD for p in ps)

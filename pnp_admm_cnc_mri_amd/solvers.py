@@ -12,7 +12,9 @@ bypass the file system through the extra keyword arguments
     images=   [B,H,W] uint8 (or float in [0,1]) ground-truth slices instead of testsets/<Set>
     y=        [B,H,W] complex measurements (skips the synthesis  y = fft2(img)*mask + noises)
     mask_id=  [B] index into `mask` when `mask` is a bank [K,H,W]            (build extension)
-    testsets=, testset_name=, results=, save_E=, device=, return_info=
+    testsets=, testset_name=, results=, save_E=, return_info=
+    device=None  HIP device index; None = LOCAL_RANK when a torch.distributed process group is initialised (one process per
+              GPU), else 0
     return_device=False   True: `out` is ONE torch tensor [B,H,W] on the device (float32; float64 with precision='f64') instead of the
               22-slot list of host arrays -- no device-to-host copy of the reconstructions; what sharding.solve_sharded hands
               to the final RCCL gather
@@ -61,12 +63,31 @@ def logger_info(logger_name, log_path):
     return log
 
 
+def resolve_device(device=None):
+    """The HIP device index an entry point runs on.  An explicit `device=` wins; the default (None) is this process's
+    LOCAL_RANK when a `torch.distributed` process group is initialised -- one process per GPU: rank r of an
+    8-rank job must not land on the root's card -- and 0 otherwise (the reference's single-process usage, S4:83)."""
+    if isinstance(device, (int, np.integer)):
+        return int(device)
+    if device is not None and getattr(device, 'index', None) is not None:      # torch.device('cuda', 3)
+        return int(device.index)
+    if device is not None and not hasattr(device, 'index'):
+        return int(device)
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return int(os.environ.get('LOCAL_RANK', 0))
+    except ImportError:                                               # no torch: the plain solvers need none
+        pass
+    return 0
+
+
 class _Job:
     """Everything around the hot loop that ADMM_L1 / ADMM_CNC / the PnP solvers share:
     inputs (S4:83-109), outputs and metrics (S4:138-172)."""
 
     def __init__(self, mask, noises, tag, suffix, images=None, y=None, mask_id=None, testsets='testsets',
-                 testset_name='Set1', results='results', save_E=None, device=0, log=None, ssim=None,
+                 testset_name='Set1', results='results', save_E=None, device=None, log=None, ssim=None,
                  psnr_fmt='{:.4f}', precision='f32'):
         # psnr_fmt: S1:150 and S3:320 print the per-image PSNR with two decimals, S4:155 / S6:332 / S6:548 with four
         self.tag, self.suffix, self.psnr_fmt = tag, suffix, psnr_fmt
@@ -109,7 +130,7 @@ class _Job:
             self.y = self.y[None]
         self.B = len(self.gt_u8) if self.gt_u8 is not None else len(self.y)
         self.noises = None if noises is None else np.asarray(noises)
-        self.device = device
+        self.device = resolve_device(device)
         self.ssim = True if ssim is None else ssim
         self.log = log
         if self.log is None and (self.from_files or self.save_E):
@@ -180,7 +201,7 @@ def _device_x(eng, job):
 
 
 def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets', testset_name='Set1',
-            results='results', save_E=None, device=0, return_info=False, precision='f32', return_device=False, **ADMM_L1_opts):
+            results='results', save_E=None, device=None, return_info=False, precision='f32', return_device=False, **ADMM_L1_opts):
     """ADMM with L1 prox on the MI355X engine.  Reference: "【1】ADMM_L1.py":29-169."""
     iter_num = ADMM_L1_opts.get('iter_num', 20)          # S1:35
     lambda1 = ADMM_L1_opts.get('lambda1', 0.04)          # S1:36
@@ -195,7 +216,7 @@ def ADMM_L1(mask, noises, images=None, y=None, mask_id=None, testsets='testsets'
 
 
 def ADMM_CNC(mask, noises, images=None, y=None, mask_id=None, testsets='testsets', testset_name='Set1',
-             results='results', save_E=None, device=0, return_info=False, precision='f32', return_device=False, **ADMM_CNC_opts):
+             results='results', save_E=None, device=None, return_info=False, precision='f32', return_device=False, **ADMM_CNC_opts):
     """ADMM with the convex-non-convex z-step.  Reference: "【4】ADMM_CNC .py":31-174."""
     iter_num = ADMM_CNC_opts.get('iter_num', 4)          # S4:37
     alpha = ADMM_CNC_opts.get('alpha', 0.4)              # S4:38

@@ -35,7 +35,7 @@ import numpy as np
 
 from . import denoisers as D
 from . import utils_pnp as pnp
-from .solvers import _Job
+from .solvers import _Job, resolve_device
 
 PRESETS = {
     # PNP_ADMM_CNC_D(alpha, iter, lambda1, reo, b), S6:569-577
@@ -106,7 +106,7 @@ def _finish_pnp(torch, job, eng, x, extra, return_device=False):
 
 
 def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
-                   testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
+                   testset_name='Set1', results='results', save_E=None, device=None, return_info=False,
                    model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False,
                    **PNP_ADMM_CNC_D_opts):
     """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
@@ -116,6 +116,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
     lambda1 = PNP_ADMM_CNC_D_opts.get('lambda1', 2.75)
     reo = PNP_ADMM_CNC_D_opts.get('reo', 1)
     b = PNP_ADMM_CNC_D_opts.get('b', 1)
+    device = resolve_device(device)                                    # None: LOCAL_RANK under a process group, else 0
     dev = torch.device('cuda', device)
     job = _Job(mask, noises, model_name, 'PNP_ADMM_CNC_D', images, y, mask_id, testsets, testset_name, results,
                save_E, device)
@@ -140,7 +141,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
 
 
 def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
-                       testsets='testsets', testset_name='Set1', results='results', save_E=None, device=0,
+                       testsets='testsets', testset_name='Set1', results='results', save_E=None, device=None,
                        return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
                        cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False, **opts):
     """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
@@ -152,6 +153,7 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
     lambda1 = opts.get('lambda1', 2.75)
     reo = opts.get('reo', 1)
     b = opts.get('b', 1)
+    device = resolve_device(device)                                    # None: LOCAL_RANK under a process group, else 0
     dev = torch.device('cuda', device)
     job = _Job(mask, noises, model_name1 + '_' + model_name2, 'PNP_ADMM_CNC_DnCNN', images, y, mask_id, testsets,
                testset_name, results, save_E, device)
@@ -177,13 +179,14 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
 
 
 def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
-                  testset_name='Set1', results='results', save_E=None, device=0, return_info=False,
+                  testset_name='Set1', results='results', save_E=None, device=None, return_info=False,
                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False,
                   **PNP_ADMM_L1_D_opts):
     """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
     import torch
     iter_num = PNP_ADMM_L1_D_opts.get('iter_num', 20)      # S3:83-84
     reo = PNP_ADMM_L1_D_opts.get('reo', 0.04)
+    device = resolve_device(device)                                    # None: LOCAL_RANK under a process group, else 0
     dev = torch.device('cuda', device)
     fam = D.family(model_name)
     x8 = fam in ('drunet', 'ffdnet')                       # x8 = True (S3:87) survives only there (S3:130,142,181)

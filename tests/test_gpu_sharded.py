@@ -90,3 +90,56 @@ def test_return_device_hands_back_the_reconstructions_as_one_device_tensor(tmp_p
     host = SP.PNP_ADMM_L1_D('ffdnet_gray', masks, None, model=sd, iter_num=2, reo=0.25, **kw)
     dev = SP.PNP_ADMM_L1_D('ffdnet_gray', masks, None, model=sd, iter_num=2, reo=0.25, return_device=True, **kw)
     assert torch.is_tensor(dev) and np.array_equal(dev.cpu().numpy().astype(np.float64), np.stack([host[b] for b in range(7)]))
+
+
+def _worker_rccl(port, q):
+    """one rank on RCCL: the real backend's first contact with solve_sharded (a child process: the suite's own process must not keep
+    a process group)"""
+    import torch
+    import torch.distributed as dist
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import sharding
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        masks, y, mid = _problem()
+        seen = {}
+        real_gather = sharding.gather_slices
+
+        def spy(x_local, B_total, dst=0, group=None):
+            seen['device'], seen['dtype'] = x_local.device, x_local.dtype
+            return real_gather(x_local, B_total, dst=dst, group=group)
+        sharding.gather_slices = spy
+        # the documented way for a bound solver: device in the partial, NOT in solve_sharded's keywords
+        bound = functools.partial(P.ADMM_CNC, device=0, results='/tmp/pnp_sharded_results_rccl')
+        x = sharding.solve_sharded(bound, masks, None, y=y, mask_id=mid, **P.PRESETS['ADMM_CNC'])
+        # and the default: no device anywhere -> LOCAL_RANK under the process group
+        x_default = sharding.solve_sharded(functools.partial(P.ADMM_CNC, results='/tmp/pnp_sharded_results_rccl'), masks, None, y=y,
+                                           mask_id=mid, **P.PRESETS['ADMM_CNC'])
+        q.put((x, x_default, str(seen['device']), str(seen['dtype'])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_solve_sharded_through_rccl_with_one_rank():
+    """`solve_sharded` on the 'nccl' (= RCCL) backend, one rank, the solver's device bound with functools.partial: the gather is handed
+    the tensor on the rank's own card and the result is bit-equal to the plain call."""
+    import torch.multiprocessing as mp
+    import pnp_admm_cnc_mri_amd as P
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(port, q))
+    p.start()
+    x, x_default, dev, dt = q.get(timeout=300)
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    assert dev == 'cuda:0' and dt == 'torch.float32'
+    masks, y, mid = _problem()
+    out = P.ADMM_CNC(masks, None, y=y, mask_id=mid, results='/tmp/pnp_sharded_results_ref', **P.PRESETS['ADMM_CNC'])
+    ref = np.stack([out[b].astype(np.float32) for b in range(len(y))])
+    assert np.array_equal(x, ref) and np.array_equal(x_default, ref)

@@ -264,3 +264,63 @@ def test_world_eight_with_the_shard_counts_of_configs_4_and_5():
         masks, y, mid = _tiny_problem(B)
         ref = sharding.solve_sharded(_tiny_solver, masks, None, y=y, mask_id=mid)
         assert got[B].shape == (B, 8, 8) and got[B].dtype == np.float32 and np.array_equal(got[B], ref), B
+
+
+# ---- round 6: the collective's device and the entry points' default device (first contact with 8 GPUs) ----
+class _OnCard:
+    """what collective_device looks at of a tensor: where it lies"""
+    def __init__(self, index):
+        self.is_cuda, self.device = index is not None, (torch.device('cuda', index) if index is not None else torch.device('cpu'))
+
+
+def test_the_collective_runs_on_the_card_the_result_lies_on(monkeypatch):
+    """A solver bound to its GPU with functools.partial(..., device=3) never shows `device` to solve_sharded: RCCL must get the tensor
+    on cuda:3 where it already is -- not a copy onto cuda:0, the root's card (round 5: `kw.get('device', 0)`)."""
+    assert sharding.collective_device(_OnCard(3), 'nccl') == torch.device('cuda', 3)
+    assert sharding.collective_device(_OnCard(3), 'nccl', device=0) == torch.device('cuda', 3)      # where the data IS wins
+    assert sharding.collective_device(_OnCard(5), 'gloo') == torch.device('cpu')
+    # a CPU tensor under nccl (an empty shard; a list-returning solver): explicit device=, else the process's LOCAL_RANK
+    assert sharding.collective_device(_OnCard(None), 'nccl', device=6) == torch.device('cuda', 6)
+    monkeypatch.setenv('LOCAL_RANK', '5')
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    assert sharding.collective_device(_OnCard(None), 'nccl') == torch.device('cuda', 5)
+
+
+def test_the_default_device_is_the_local_rank_under_a_process_group(monkeypatch):
+    from pnp_admm_cnc_mri_amd.solvers import resolve_device
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert resolve_device(None) == 0                      # no process group: the reference's single-process usage
+    assert resolve_device(2) == 2 and resolve_device(torch.device('cuda', 4)) == 4
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    assert resolve_device(None) == 3                      # one process per GPU: rank r works on its own card
+    assert resolve_device(1) == 1                         # an explicit device= still wins
+
+
+def _strict_solver(mask, noises, y=None, mask_id=None, iter_num=2):
+    """no return_device keyword, no **opts, float64 list out: the reference's own call shape"""
+    return [O.admm_l1(y[n], mask[int(mask_id[n])], iter_num) for n in range(len(y))]
+
+
+def test_solve_sharded_passes_the_partial_solvers_tensor_to_the_collective(monkeypatch, tmp_path):
+    """solve_sharded under a (one-rank, gloo) process group: the collective runs -- a one-rank group is not short-circuited -- on the
+    device collective_device picks from the solver's OWN result, and a solver without the `return_device` keyword is called without
+    it, its float64 list cast to the gather's dtype (advisor, round 5)."""
+    import functools
+    seen = {}
+    real_cd = sharding.collective_device
+
+    def spy(x_local, backend, device=None):
+        seen['x'], seen['backend'], seen['device_kw'] = x_local, backend, device
+        return real_cd(x_local, backend, device)
+    monkeypatch.setattr(sharding, 'collective_device', spy)
+    dist.init_process_group('gloo', rank=0, world_size=1, init_method='file://%s' % (tmp_path / 'rdv'))
+    try:
+        masks, _, y, mid = _solver_problem()
+        got = sharding.solve_sharded(functools.partial(_fake_solver, iter_num=2), masks, None, y=y, mask_id=mid)
+        assert seen['backend'] == 'gloo' and seen['device_kw'] is None and torch.is_tensor(seen['x']) and seen['x'].shape[0] == 5
+        strict = sharding.solve_sharded(_strict_solver, masks, None, y=y, mask_id=mid, iter_num=2)
+    finally:
+        dist.destroy_process_group()
+    ref = sharding.solve_sharded(_fake_solver, masks, None, y=y, mask_id=mid, iter_num=2)        # no group: a plain call
+    assert np.array_equal(got, ref)
+    assert strict.dtype == np.float32 and np.array_equal(strict, ref)
