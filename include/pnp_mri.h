@@ -84,7 +84,8 @@ int pnp_get_plan(pnp_ctx* ctx, int* queues, int* chunk, int* launches_per_iterat
  * Replaces the per-image `y`, `index = np.nonzero(mask)` set-up of S4:101-106.
  * A new problem (this call, pnp_synthesize_problem and their _f64 forms) INVALIDATES the ADMM state and x of the problem before it:
  * z, w and x are undefined until pnp_init_state, or pnp_set_state with BOTH z and w, has run -- the reference likewise builds z and w
- * anew per image (S4:103-109). */
+ * anew per image (S4:103-109).  Until then every entry point that would read them (pnp_admm_l1_run, pnp_admm_cnc_run, pnp_get_state,
+ * pnp_set_state with only one of z / w, and their _f64 forms) returns PNP_E_STATE. */
 int pnp_upload_problem(pnp_ctx* ctx, const float* y, const uint8_t* mask_bank,
                        const int32_t* mask_id, int B, int K, int on_device);
 

@@ -63,6 +63,7 @@ struct pnp_ctx {
     hipStream_t stream = nullptr;
     bool fast = true;
     bool have_x = false;
+    bool have_state = false;         // z / w hold a defined state for the CURRENT problem: cleared by upload / synthesize, set by pnp_init_state or pnp_set_state(z, w)
     float2* y = nullptr;              // [Bmax][H][W]
     float2* work = nullptr;           // [Bmax][H][W] transform intermediate
     float *z = nullptr, *w = nullptr, *x = nullptr;
@@ -278,6 +279,7 @@ int pnp_ctx_destroy(pnp_ctx* c) {
 
 #define CTX(c) do { if (!(c)) return fail(PNP_E_ARG, "%s: ctx is null", __func__); HIPCHK(hipSetDevice((c)->device)); } while (0)
 #define NEED_PROBLEM(c) do { if ((c)->B <= 0) return fail(PNP_E_STATE, "%s: no problem uploaded", __func__); } while (0)
+#define NEED_STATE(c) do { if (!(c)->have_state) return fail(PNP_E_STATE, "%s: z / w are undefined since the last upload / synthesize (call pnp_init_state or pnp_set_state with both z and w)", __func__); } while (0)
 #define F32_ONLY(c) do { if ((c)->f64) return fail(PNP_E_STATE, "%s: not available on an fp64 validation context", __func__); } while (0)
 #define F64_ONLY(c) do { if (!(c)->f64) return fail(PNP_E_STATE, "%s: needs a context made by pnp_ctx_create_f64", __func__); } while (0)
 
@@ -410,6 +412,7 @@ int pnp_upload_problem(pnp_ctx* c, const float* y, const uint8_t* mask_bank, con
     // order flag is reset with it -- a conversion under the new B would read the slice path's padded arrays beyond the old batch.
     c->state_sliced = false;
     c->have_x = false;
+    c->have_state = false;
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     rc = copy_in(c, c->y, y, (size_t)B * c->N * sizeof(float2), on_device);
@@ -425,6 +428,7 @@ int pnp_synthesize_problem(pnp_ctx* c, const float* img, const float* noise, int
     // order flag is reset with it -- a conversion under the new B would read the slice path's padded arrays beyond the old batch.
     c->state_sliced = false;
     c->have_x = false;
+    c->have_state = false;
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     const size_t img_bytes = (size_t)B * c->N * sizeof(float);
@@ -472,6 +476,7 @@ int pnp_init_state(pnp_ctx* c) {
         HIPCHK(launch_rows<double>(c->stream, c->W, IN_COMPLEX, true, EPI_ABS_COMPLEX, ra));
         HIPCHK(hipMemsetAsync(c->wd, 0, (size_t)c->B * c->N * sizeof(double), c->stream));
         c->have_x = false;
+        c->have_state = true;
         return PNP_OK;
     }
     c->state_sliced = false;                           // both arrays are rewritten below, in natural order
@@ -483,6 +488,7 @@ int pnp_init_state(pnp_ctx* c) {
     HIPCHK(launch_rows(c->stream, c->W, IN_COMPLEX, true, EPI_ABS_COMPLEX, ra));
     HIPCHK(hipMemsetAsync(c->w, 0, (size_t)c->B * c->N * sizeof(float), c->stream));
     c->have_x = false;
+    c->have_state = true;
     return PNP_OK;
 }
 
@@ -491,15 +497,16 @@ int pnp_set_state(pnp_ctx* c, const float* z, const float* w, int on_device) {
     const size_t bytes = (size_t)c->B * c->N * sizeof(float);
     int rc;
     if (z && w) c->state_sliced = false;               // both replaced: nothing to convert
-    else if ((rc = state_order(c, false))) return rc;
+    else { NEED_STATE(c); if ((rc = state_order(c, false))) return rc; }      // one of the two kept: it must be defined
     if (z) { rc = copy_in(c, c->z, z, bytes, on_device); if (rc) return rc; }
     if (w) { rc = copy_in(c, c->w, w, bytes, on_device); if (rc) return rc; }
     c->have_x = false;
+    if (z && w) c->have_state = true;
     return PNP_OK;
 }
 
 int pnp_get_state(pnp_ctx* c, float* z, float* w, int on_device) {
-    CTX(c); F32_ONLY(c); NEED_PROBLEM(c);
+    CTX(c); F32_ONLY(c); NEED_PROBLEM(c); NEED_STATE(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(float);
     int rc;
     if ((rc = state_order(c, false))) return rc;
@@ -589,7 +596,7 @@ static int check_thresholds(const char* who, double alpha, double lambda1, doubl
 }
 
 int pnp_admm_l1_run(pnp_ctx* c, int iters, double lambda1, double reo) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); NEED_PROBLEM(c); NEED_STATE(c);
     Range r("pnp_admm_l1_run");
     if (int rv = check_thresholds("pnp_admm_l1_run", 0.0, lambda1, reo)) return rv;
     if (c->f64) {
@@ -601,7 +608,7 @@ int pnp_admm_l1_run(pnp_ctx* c, int iters, double lambda1, double reo) {
 }
 
 int pnp_admm_cnc_run(pnp_ctx* c, int iters, double alpha, double lambda1, double reo, double b) {
-    CTX(c); NEED_PROBLEM(c);
+    CTX(c); NEED_PROBLEM(c); NEED_STATE(c);
     Range r("pnp_admm_cnc_run");
     if (!(b > 0.0)) return fail(PNP_E_ARG, "pnp_admm_cnc_run: b must be > 0");
     if (int rv = check_thresholds("pnp_admm_cnc_run", alpha, lambda1, reo)) return rv;
@@ -810,6 +817,7 @@ int pnp_ssim_f64(pnp_ctx* c, const double* x, const uint8_t* gt, int gt_on_devic
 int pnp_upload_problem_f64(pnp_ctx* c, const double* y, const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
     CTX(c); F64_ONLY(c);
     if (!y) return fail(PNP_E_ARG, "pnp_upload_problem_f64: y is null");
+    c->have_x = false; c->have_state = false;           // a new problem: z / w undefined until pnp_init_state / pnp_set_state_f64(z, w)
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     rc = copy_in(c, c->yd, y, (size_t)B * c->N * sizeof(double2), on_device);
@@ -824,6 +832,7 @@ int pnp_synthesize_problem_f64(pnp_ctx* c, const float* img, const double* noise
                                const uint8_t* mask_bank, const int32_t* mask_id, int B, int K, int on_device) {
     CTX(c); F64_ONLY(c);
     if (!img || !noise) return fail(PNP_E_ARG, "pnp_synthesize_problem_f64: img/noise is null");
+    c->have_x = false; c->have_state = false;
     int rc = set_masks(c, mask_bank, mask_id, B, K, on_device);
     if (rc) { c->B = 0; return rc; }
     const size_t img_bytes = (size_t)B * c->N * sizeof(float);
@@ -865,14 +874,16 @@ int pnp_set_state_f64(pnp_ctx* c, const double* z, const double* w, int on_devic
     CTX(c); F64_ONLY(c); NEED_PROBLEM(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(double);
     int rc;
+    if (!(z && w)) NEED_STATE(c);                          // one of the two kept: it must be defined
     if (z) { rc = copy_in(c, c->zd, z, bytes, on_device); if (rc) return rc; }
     if (w) { rc = copy_in(c, c->wd, w, bytes, on_device); if (rc) return rc; }
     c->have_x = false;
+    if (z && w) c->have_state = true;
     return PNP_OK;
 }
 
 int pnp_get_state_f64(pnp_ctx* c, double* z, double* w, int on_device) {
-    CTX(c); F64_ONLY(c); NEED_PROBLEM(c);
+    CTX(c); F64_ONLY(c); NEED_PROBLEM(c); NEED_STATE(c);
     const size_t bytes = (size_t)c->B * c->N * sizeof(double);
     int rc;
     if (z) { rc = copy_out(c, z, c->zd, bytes, on_device); if (rc) return rc; }
@@ -968,6 +979,8 @@ int pnp_conv3x3_tail_add_nchw_f16x3(void* stream, const float* x, const float* x
                                     int H, int W) {
     if (!x || !x2 || !w || !y) return fail(PNP_E_ARG, "pnp_conv3x3_tail_add_nchw_f16x3: null pointer");
     if (n < 1 || H < 1 || W < 1 || cout < 1 || cout > 4) return fail(PNP_E_ARG, "pnp_conv3x3_tail_add_nchw_f16x3: n, H, W >= 1 and 1 <= cout <= 4 required");
+    if ((long long)H * W * 64 * 4 > 0x7fffffffLL) return fail(PNP_E_ARG, "pnp_conv3x3_tail_add_nchw_f16x3: an image of %d x %d x 64 floats exceeds 2 GiB", H, W);
+    if (x == y || x2 == y) return fail(PNP_E_ARG, "pnp_conv3x3_tail_add_nchw_f16x3: y must not alias x or x2");
     HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, x2, w, bias, y, n, cout, H, W));
     return PNP_OK;
 }
@@ -975,32 +988,34 @@ int pnp_ffdnet_head_nhwc(void* stream, const float* x, const float* sigma, int s
                          int n, int h, int wd, int relu) {
     if (!x || !sigma || !w || !y) return fail(PNP_E_ARG, "pnp_ffdnet_head_nhwc: null pointer");
     if (n < 1 || h < 1 || wd < 1) return fail(PNP_E_ARG, "pnp_ffdnet_head_nhwc: n, h, w must be >= 1");
+    if ((long long)((h + 1) / 2) * ((wd + 1) / 2) * 64 * 4 > 0x7fffffffLL) return fail(PNP_E_ARG, "pnp_ffdnet_head_nhwc: a result of %d x %d x 64 floats exceeds 2 GiB", (h + 1) / 2, (wd + 1) / 2);
     HIPCHK(launch_ffdnet_head((hipStream_t)stream, x, sigma, sigma_per_image != 0, w, bias, y, n, h, wd, relu));
     return PNP_OK;
 }
 int pnp_ffdnet_tail_f16x3(void* stream, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd) {
     if (!x || !w || !y) return fail(PNP_E_ARG, "pnp_ffdnet_tail_f16x3: null pointer");
     if (n < 1 || h < 1 || wd < 1) return fail(PNP_E_ARG, "pnp_ffdnet_tail_f16x3: n, h, w must be >= 1");
+    if ((long long)((h + 1) / 2) * ((wd + 1) / 2) * 64 * 4 > 0x7fffffffLL) return fail(PNP_E_ARG, "pnp_ffdnet_tail_f16x3: an input of %d x %d x 64 floats exceeds 2 GiB", (h + 1) / 2, (wd + 1) / 2);
     HIPCHK(launch_conv3x3_tail_f16x3((hipStream_t)stream, x, nullptr, w, bias, y, n, 4, (h + 1) / 2, (wd + 1) / 2, h, wd));
     return PNP_OK;
 }
-static int pix2_args(const char* who, const float* x, const float* w, const float* y, int n, int C, int H, int W, int up) {
+static int pix2_args(const char* who, const float* x, const float* x2, const float* w, const float* y, int n, int C, int H, int W, int up) {
     if (!x || !w || !y) return fail(PNP_E_ARG, "%s: null pointer", who);
     if (n < 1 || H < 1 || W < 1) return fail(PNP_E_ARG, "%s: n, H, W must be >= 1", who);
     if (C < 64 || C > 1024 || C % (up ? 128 : 64)) return fail(PNP_E_ARG, "%s: C must be a multiple of %d in 64..1024 (got %d)", who, up ? 128 : 64, C);
     if (!up && ((H | W) & 1)) return fail(PNP_E_ARG, "%s: H and W must be even (got %d x %d)", who, H, W);
     const long long in_b = (long long)H * W * C * 4, out_b = up ? in_b * 2 : in_b / 2;
     if (in_b > 0x7fffffffLL || out_b > 0x7fffffffLL) return fail(PNP_E_ARG, "%s: an image of %d x %d x %d floats (or its result) exceeds 2 GiB", who, H, W, C);
-    if (x == y) return fail(PNP_E_ARG, "%s: y must not alias x", who);
+    if (x == y || x2 == y) return fail(PNP_E_ARG, "%s: y must not alias x or x2 (tiles are re-read after their neighbours were written)", who);
     return PNP_OK;
 }
 int pnp_conv2x2s2_nhwc_f16x3(void* stream, const float* x, const float* x2, const float* w, float* y, int n, int C, int H, int W) {
-    if (int rc = pix2_args("pnp_conv2x2s2_nhwc_f16x3", x, w, y, n, C, H, W, 0)) return rc;
+    if (int rc = pix2_args("pnp_conv2x2s2_nhwc_f16x3", x, x2, w, y, n, C, H, W, 0)) return rc;
     HIPCHK(launch_pix2x2_f16x3((hipStream_t)stream, x, x2, w, y, n, C, H, W, 0));
     return PNP_OK;
 }
 int pnp_convT2x2s2_nhwc_f16x3(void* stream, const float* x, const float* x2, const float* w, float* y, int n, int C, int H, int W) {
-    if (int rc = pix2_args("pnp_convT2x2s2_nhwc_f16x3", x, w, y, n, C, H, W, 1)) return rc;
+    if (int rc = pix2_args("pnp_convT2x2s2_nhwc_f16x3", x, x2, w, y, n, C, H, W, 1)) return rc;
     HIPCHK(launch_pix2x2_f16x3((hipStream_t)stream, x, x2, w, y, n, C, H, W, 1));
     return PNP_OK;
 }

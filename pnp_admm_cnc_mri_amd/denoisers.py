@@ -900,14 +900,16 @@ class Denoiser:
         find = (min(B, self.cnn_batch) >= 16 and x.is_cuda) if self.miopen_find == 'auto' else bool(self.miopen_find)
         if self.backend in HIP_BACKENDS and isinstance(self.model, _PlainStack) and hip_covers_stack(self.model.model):
             find = False                      # no MIOpen call in this forward: the process-global flag is left alone
-        if isinstance(self.model, UNetRes) and self.model.hip_covers():
-            find = False                      # DRUNet under 'hip_f16x3': every layer on libpnpmri.so (sizes that are no multiple of 8 fall back inside forward)
+        if isinstance(self.model, UNetRes) and self.model.hip_covers(*(-(-d // 16) * 16 for d in x.shape[-2:])):
+            find = False                      # DRUNet under 'hip_f16x3': every layer on libpnpmri.so at the size the model is CALLED with -- test_mode pads to
+                                              # multiples of 16 (_one, utils/utils_model.py:60-68), so three halvings always survive
         cd = torch.backends.cudnn
         before = cd.benchmark
         cd.benchmark = bool(find or before)
         try:
             for b0 in range(0, B, self.cnn_batch):
-                if self.cnn_dtype is None and self.backend == 'hip_f16x3' and isinstance(self.model, FFDNet) and x.is_cuda and out.is_contiguous():
+                if (self.cnn_dtype is None and self.backend == 'hip_f16x3' and isinstance(self.model, FFDNet) and x.is_cuda and out.is_contiguous()
+                        and out.dtype == torch.float32 and out.device == x.device):
                     self._one(x[b0:b0 + self.cnn_batch], i, out=out[b0:b0 + self.cnn_batch])     # no copy: the last layer writes the slice itself
                 elif self.cnn_dtype is None:
                     out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)

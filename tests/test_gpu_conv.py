@@ -291,6 +291,21 @@ def test_pix2x2_argument_errors(env):
                      (L.pnp_conv2x2_pack_f16x3, (s, p(x), p(x), 128, 0))):                                # aliased
         with pytest.raises(lib.PnpError):
             lib.check(fn(*args))
+    # round 6 (advisor): the skip input x2 must not be the output either, and images beyond 2 GiB are an argument error with a message
+    # (PNP_E_ARG), not a bare HIP error from the launcher
+    y = torch.zeros(1, 3, 3, 256, device='cuda')
+    w4 = torch.zeros(4, 64, 3, 3, device='cuda')
+    x64 = torch.zeros(1, 6, 6, 64, device='cuda')
+    y1 = torch.zeros(1, 4, 6, 6, device='cuda')
+    big = 1 << 12                                             # 4096 x 4096 x 64 floats = 4 GiB: only the sizes are checked, nothing is touched
+    for fn, args in ((L.pnp_conv2x2s2_nhwc_f16x3, (s, p(x), p(y), p(x), p(y), 1, 128, 6, 6)),              # y aliases x2
+                     (L.pnp_conv3x3_tail_add_nchw_f16x3, (s, p(x64), p(y1), p(w4), None, p(y1), 1, 4, 6, 6)),      # y aliases x2
+                     (L.pnp_conv3x3_tail_add_nchw_f16x3, (s, p(x64), p(x64), p(w4), None, p(y1), 1, 4, big, big)),
+                     (L.pnp_ffdnet_tail_f16x3, (s, p(x64), p(w4), None, p(y1), 1, 2 * big, 2 * big)),
+                     (L.pnp_ffdnet_head_nhwc, (s, p(y1), p(y1), 0, p(w4), None, p(x64), 1, 2 * big, 2 * big, 1))):
+        with pytest.raises(lib.PnpError) as e:
+            lib.check(fn(*args))
+        assert e.value.code == -1, (fn.__name__, e.value.code)              # PNP_E_ARG (include/pnp_mri.h)
 
 
 def test_relayout_round_trip_and_argument_errors(env):

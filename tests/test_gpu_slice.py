@@ -285,9 +285,11 @@ def test_state_order_is_private_to_the_slice_path(P, golden_inputs, monkeypatch)
 
 def test_a_new_problem_invalidates_the_state_of_the_one_before_it(P, golden_inputs):
     """include/pnp_mri.h: an upload makes z / w undefined until pnp_init_state or pnp_set_state(z, w).  After a slice-resident loop
-    (state in the kernel's own order) a problem with ANOTHER batch size is uploaded: get_state before any initialisation must not
-    convert under the new batch size (that read the padded arrays beyond the old batch) -- it returns, whatever the values; then
-    both ways of defining the state give the loop of a fresh context."""
+    (state in the kernel's own order) a problem with ANOTHER batch size is uploaded: every entry point that would READ z / w before
+    they are defined again -- get_state, the loops, set_state with only one of the two -- returns PNP_E_STATE (round 6: round 5 only
+    guaranteed defined behaviour, and a run straight after the upload read the previous problem's state in the wrong order); then both
+    ways of defining the state give the loop of a fresh context."""
+    from pnp_admm_cnc_mri_amd import _lib
     B0, B1 = 64, 96
     masks, mid, ys = _problem(golden_inputs, B1)
     args = (0.45, 0.5, 0.05, 64)
@@ -303,9 +305,13 @@ def test_a_new_problem_invalidates_the_state_of_the_one_before_it(P, golden_inpu
         eng.admm_cnc(2, *args)
         assert eng.path_name == 'slice'
         eng.upload(ys, masks, mid)                                  # B0 -> B1 with the state still in the slice order
-        z, w = eng.get_state()                                      # undefined values, defined behaviour
-        assert z.shape == (B1, 256, 256) and w.shape == (B1, 256, 256)
+        for call in (eng.get_state, lambda: eng.admm_cnc(1, *args), lambda: eng.admm_l1(1, 0.05, 0.5), lambda: eng.set_state(z=z0)):
+            with pytest.raises(_lib.PnpError) as e:
+                call()
+            assert e.value.code == -3                               # PNP_E_STATE
         eng.init_state()
+        z, w = eng.get_state()
+        assert z.shape == (B1, 256, 256) and np.array_equal(z, z0) and not w.any()
         eng.admm_cnc(3, *args)
         assert np.array_equal(eng.x(), xr)
         eng.admm_cnc(1, *args)
