@@ -82,6 +82,11 @@ hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw /*[C][C][
 hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
                                 float* y, int n, int C /* 64 k <= 1024 */, int H, int W, int relu, int dilation /* 1..4; 1 if C > 64 */,
                                 int fmt = 0 /* bit 0: x, bit 1: skip, bit 2: y in the split activation format (f16x3_common.h) */);
+// the same layer at dilation 1 with 64 x 64 wave tiles, compute + helper waves (kernels_conv_f16x3_wide.hip): same arguments, same packed
+// weights, bit-equal results; launch_conv3x3_f16x3 dispatches to it (conv_wide_mode below) -- callers never name it
+hipError_t launch_conv3x3_f16x3_wide(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
+                                     float* y, int n, int C, int H, int W, int relu, int fmt);
+int conv_wide_mode();            // developer knob PNP_CONV_WIDE, read once: unset / -1 = by size, 0 = never, 1 = always (dilation 1)
 hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc /* null or added to x */, const float* w_oihw,
                                      const float* bias, float* y_nchw, int n, int cout, int H, int W,
                                      int shuffle_h = 0, int shuffle_w = 0 /* FFDNet: cout = 4 written as one pixel-shuffled [shuffle_h][shuffle_w] channel */);

@@ -32,6 +32,7 @@
 #include "conv_common.h"
 #include "f16x3_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace pnp {
 
@@ -580,6 +581,13 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, c
     if ((long long)H * W * C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;           // one image must fit a signed 32-bit buffer offset
     const int cus = conv_compute_units();
     if (cus <= 0) return hipGetLastError();
+    if (dilation == 1) {
+        // the wide kernel (kernels_conv_f16x3_wide.hip: 16 x 16 tiles, ONE workgroup per compute unit) once every workgroup has at least two
+        // items of its own -- below that the 8 x 16 tiles on two workgroups per unit spread a small layer better
+        const long long items16 = (long long)n * ((W + 15) / 16) * ((H + 15) / 16) * (C >> 6);
+        const int mode = conv_wide_mode();
+        if (mode == 1 || (mode < 0 && false && items16 >= 2LL * cus))      /* auto: OFF until the GPU parity run of this round has passed */ return launch_conv3x3_f16x3_wide(s, x, w, bias, skip, y, n, C, H, W, relu, fmt);
+    }
     switch (dilation) {
         case 1: return launch_h3_dil<1>(s, a, items, cus);
         case 2: return launch_h3_dil<2>(s, a, items, cus);
@@ -587,6 +595,11 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, c
         case 4: return launch_h3_dil<4>(s, a, items, cus);
         default: return hipErrorInvalidValue;
     }
+}
+
+int conv_wide_mode() {
+    static const int mode = [] { const char* e = getenv("PNP_CONV_WIDE"); return e ? atoi(e) : -1; }();
+    return mode;
 }
 
 hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw, float* wfrag, int C) {

@@ -1,0 +1,417 @@
+// The conv3x3 C -> C layer of kernels_conv_f16x3.hip (split-half arithmetic) with a 64 x 64 WAVE TILE and the work of a
+// workgroup divided between two kinds of waves: "wide".  Round 6; models/basicblock.py:63-100, network_ffdnet.py:58-73, network_unet.py:95-136.
+//
+// Why.  The round-5 counters of k_conv3x3_c64_h3<1> (profiles/pmc_conv_f16x3_r05.txt) show the matrix pipe busy 0.55 of the cycles on
+// random and on zero data alike: the rest is not power but what every wave does besides its MFMAs -- per tap of 48 MFMAs a wave also issues
+// four LDS-DMAs, two prefetch loads, 24 ds_read_b128, counted waits and a barrier, and per item the split of the next input tile, its LDS
+// writes and an epilogue staged through LDS.  Here
+//   * a wave owns 64 pixels (4 tile rows of 16) x 64 output channels: 96 MFMAs per tap for 32 ds_read_b128 (one read per three MFMAs
+//     instead of one per two), and a tap's 16 KiB of weights serve 256 pixels instead of 128;
+//   * ONE workgroup of 512 threads per compute unit: waves 0-3 COMPUTE -- their instruction stream inside a tap is LDS reads and MFMAs and
+//     nothing else --, waves 4-7 (one beside each compute wave on its SIMD) are HELPERS: they issue every LDS-DMA of the weight stream, fetch
+//     the next input tile into registers piece by piece, split it and write it into LDS between two chunks, and count the waits; what
+//     they do overlaps the partner's MFMAs instead of interrupting them;
+//   * weights are TRIPLE-buffered: at the barrier that opens tap T the weights of taps T and T + 1 have landed, so a compute wave reads
+//     its first fragments of tap T + 1 before that tap's barrier -- after a barrier the next instruction is an MFMA;
+//   * the matrix product is taken TRANSPOSED (A = weights: M = output channels, B = pixels): an accumulator quad of a lane is then four
+//     consecutive channels of ONE pixel and leaves as a 16-byte store straight from the registers -- no LDS staging, no wave barrier, no
+//     second workgroup barrier per item.  For the split activation format two v_permlane16_swap per store pair the lane rows up so that
+//     each lane still stores 16 bytes (eight hi halves or eight lo halves).
+// The arithmetic is the narrow kernel's, instruction for instruction per output value (same products, same order of accumulation):
+// tests/test_gpu_conv.py holds the two kernels BIT-equal.  16 x 16 pixel tiles: 88 KiB of input tile + 48 KiB of weights in LDS.
+#include "conv_common.h"
+#include "f16x3_common.h"
+#include <type_traits>
+
+namespace pnp {
+
+constexpr int WT_TX = 16, WT_TY = 16;                            // output tile
+constexpr int WT_HX = WT_TX + 2, WT_HY = WT_TY + 2;              // with halo
+constexpr int WT_PSB = CV_PS * 4;                                // bytes between consecutive pixels of the LDS tile (272)
+constexpr int WT_XIN = WT_HY * WT_HX * CV_PS;                    // floats of the input tile (88 128 bytes)
+constexpr int WT_HTHREADS = 256;                                 // helper threads
+constexpr int WT_XU = (WT_HY * WT_HX * 16 + WT_HTHREADS - 1) / WT_HTHREADS;     // 16-byte chunks of the tile per helper thread: 21
+constexpr int WT_THREADS = 512;
+constexpr int WT_NBUF = 3;                                       // weight buffers (a chunk has 9 taps: buffer of tap t = t % 3, a constant)
+constexpr int WT_PIECE = (WT_XU + 5) / 6;                        // the next input tile is requested in six pieces, behind the DMAs of taps 0..5
+
+struct WTilePos { int img, y0, x0; };
+__device__ __forceinline__ WTilePos wtile_pos(const ConvArgs& a, int t) {
+    const int per_img = a.tiles_x * a.tiles_y;
+    WTilePos q;
+    q.img = t / per_img;
+    const int trem = t - q.img * per_img, ty = trem / a.tiles_x;
+    q.y0 = ty * WT_TY; q.x0 = (trem - ty * a.tiles_x) * WT_TX;
+    return q;
+}
+
+// ---- helper side: input staging (the narrow kernel's scheme, kernels_conv_f16x3.hip, on the 18 x 18 tile and 256 helper threads) ----
+// chunk u of helper thread h is tile pixel p = stage_pixel(h) + 16 u = (row r, column c), channels 4 (h & 15) ..; pk[u] = (r W + c) * pix | c, or -1
+__device__ __forceinline__ int wstage_pixel(int h) { const int g = h >> 4; return (g >> 1) + 8 * (g & 1); }
+struct WStaging { int pk[WT_XU]; };
+__device__ __forceinline__ void wstaging_init(const ConvArgs& a, int h, WStaging& st, const int pix) {
+#pragma unroll
+    for (int u = 0; u < WT_XU; ++u) {
+        const int p = wstage_pixel(h) + 16 * u, r = p / WT_HX, c = p - r * WT_HX;
+        st.pk[u] = (p < WT_HY * WT_HX) ? (((r * a.W + c) * pix) | c) : -1;
+    }
+}
+struct WFetch { __amdgpu_buffer_rsrc_t rs; int origin, xlo, xhi; };
+__device__ __forceinline__ WFetch wfetch_begin(const ConvArgs& a, const WTilePos& q, int h, const int pix, const int coff, const bool any = true) {
+    WFetch f;
+    // any = false: a descriptor of zero bytes -- every piece is still ISSUED (the counted waits below assume it) but none reaches memory
+    f.rs = image_rsrc(a.x + (size_t)q.img * a.H * a.W * (pix >> 2), any ? a.H : 0, a.W, pix, any ? coff : 0);
+    f.origin = ((q.y0 - 1) * a.W + (q.x0 - 1)) * pix + 16 * (h & 15);        // may be negative: such offsets are out of range as unsigned
+    f.xlo = 1 - q.x0; f.xhi = a.W + 1 - q.x0;                                // valid tile columns: xlo <= c < xhi
+    return f;
+}
+template <int U0, int U1>
+__device__ __forceinline__ void wfetch_piece(const WFetch& f, const WStaging& st, f32x4 (&v)[WT_XU]) {
+#pragma unroll
+    for (int u = U0; u < U1 && u < WT_XU; ++u) {
+        const int c = st.pk[u] & 255;
+        const bool in = st.pk[u] >= 0 && c >= f.xlo && c < f.xhi;
+        const int off = in ? f.origin + (st.pk[u] & ~255) : -16;
+        const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(f.rs, off, 0, 0);
+        v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+    }
+}
+// registers -> LDS tile (split on the way unless the tensor is in the SPLIT activation format already): put_input_h3's layout
+__device__ __forceinline__ void wput_input(float* xin, int h, const f32x4 (&v)[WT_XU], const bool in_split) {
+    if (in_split) {
+        const int q = h & 15;
+        char* px = reinterpret_cast<char*>(xin) + wstage_pixel(h) * WT_PSB + h3_chunk_pos(q & 3, (q >> 2) & 1, q >> 3);
+#pragma unroll
+        for (int u = 0; u < WT_XU; ++u)
+            if (wstage_pixel(h) + 16 * u < WT_HY * WT_HX)
+                *reinterpret_cast<f32x4*>(px + u * (16 * WT_PSB)) = v[u];
+        return;
+    }
+    const int t = h & 15;
+    char* px = reinterpret_cast<char*>(xin) + wstage_pixel(h) * WT_PSB + h3_chunk_pos((t >> 1) & 3, t >> 3, 0) + 8 * (t & 1);
+#pragma unroll
+    for (int u = 0; u < WT_XU; ++u)
+        if (wstage_pixel(h) + 16 * u < WT_HY * WT_HX) {
+            h4 hi, lo;
+            split4(v[u], hi, lo);
+            *reinterpret_cast<h4*>(px + u * (16 * WT_PSB)) = hi;
+            *reinterpret_cast<h4*>(px + u * (16 * WT_PSB) + 16) = lo;
+        }
+}
+
+// The epilogue of an item, straight from the accumulators: y = relu?(acc + bias + skip), ONE 16-byte store per lane and (ct, pt).
+// Accumulator reg r of lane (i, kb), tile (ct, pt) = channel 16 ct + 4 kb + r of pixel (tile row 4 w + pt, column h3_row_pixel(i)).
+// SKIP / KSPLIT / YSPLIT: a skip tensor is added / it is in the split activation format / y is written in it (f16x3_common.h) -- compile-time,
+// one instance each: sixteen stores behind uniform branches would put a dozen branches per store on the wave's critical path.
+// The two orders of the sum are the narrow kernel's (store_rows32 / store_rows32_fmt): all-float32 tensors acc + (skip + bias), any split
+// tensor (acc + bias) + skip.
+template <bool SKIP, bool KSPLIT, bool YSPLIT>
+__device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, const f32x4 (&mainv)[4][4], const f32x4 (&corrv)[4][4],
+                                          int wv, int lane, const int pix, const int cb) {
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, 64 * cb);
+    const __amdgpu_buffer_rsrc_t rk = image_rsrc((SKIP ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, 64 * cb);
+    // (opaque copy of the lane number: what is derived from it -- and the biases -- is computed HERE, per item; hoisted out of the item loop as
+    // the loop invariants they are, these values would live through the tap loop, which has no register to spare)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int i = ln & 15, kb = ln >> 4;
+    constexpr bool FMT = KSPLIT || YSPLIT;
+    const int gx = q.x0 + h3_row_pixel(i);
+    // byte offsets inside the pixel's block of 64 channels: float32 -- this lane's four channels 16 ct + 4 kb ..; split -- after the
+    // lane-row exchange even rows hold the eight hi halves of channels 16 ct + 8 (kb >> 1) .., odd rows the eight lo halves (+ 128)
+    const int of32 = 16 * kb, osp = 16 * (kb >> 1) + 128 * (kb & 1);
+    // ReLU without a branch: v < thr ? 0 : v with thr = 0, or -inf (never true; NaN stays NaN either way: torch.nn.ReLU)
+    const float thr = a.relu ? 0.f : -__builtin_inff();
+    f32x4 bs[4];
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias ? a.bias : a.w), 0, a.bias ? a.C * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {                             // (no bias: a descriptor of zero bytes returns zeros)
+        const u32x4v b = __builtin_amdgcn_raw_buffer_load_b128(rb, (64 * cb + 16 * ct) * 4 + 16 * kb, 0, 0);
+        bs[ct] = f32x4{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        // rows below the image: beyond the buffer's range by themselves; columns right of it: such an offset
+        const int pb = gx < a.W ? ((q.y0 + 4 * wv + pt) * a.W + gx) * pix : -256;
+        u32x4v kq[4];
+        if (SKIP) {                                              // the four requests of a tile row first: one memory round trip
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                kq[ct] = __builtin_amdgcn_raw_buffer_load_b128(rk, pb + (KSPLIT ? 32 * ct + osp : 64 * ct + of32), 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(corrv[ct][pt][r], H3_RSCALE, mainv[ct][pt][r]);
+            if (FMT) {
+                v += bs[ct];
+                if (SKIP) {
+                    if (KSPLIT) {
+                        // undo the producer's lane-row exchange: afterwards hq = this lane's four hi halves, lq its four lo halves
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(kq[ct].x, kq[ct].z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(kq[ct].y, kq[ct].w, false, false);
+                        const h4 hq = __builtin_bit_cast(h4, u32x2v{s0[0], s1[0]}), lq = __builtin_bit_cast(h4, u32x2v{s0[1], s1[1]});
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += unsplit(hq[r], lq[r]);
+                    } else {
+                        v += f32x4{__uint_as_float(kq[ct].x), __uint_as_float(kq[ct].y), __uint_as_float(kq[ct].z), __uint_as_float(kq[ct].w)};
+                    }
+                }
+            } else if (SKIP) {
+                v += f32x4{__uint_as_float(kq[ct].x), __uint_as_float(kq[ct].y), __uint_as_float(kq[ct].z), __uint_as_float(kq[ct].w)} + bs[ct];
+            } else {
+                v += bs[ct];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] < thr ? 0.f : v[r];
+            if (YSPLIT) {
+                h4 hi, lo;
+                split4(v, hi, lo);
+                const u32x2v hu = __builtin_bit_cast(u32x2v, hi), lu = __builtin_bit_cast(u32x2v, lo);
+                // odd lane rows of the hi dwords <-> even lane rows of the lo dwords (cdna_hip_programming.md T21, for rows of 16 lanes):
+                // even rows then hold [own hi | partner's hi], odd rows [partner's lo | own lo] -- eight consecutive channels each
+                const auto s0 = __builtin_amdgcn_permlane16_swap(hu.x, lu.x, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(hu.y, lu.y, false, false);
+                const u32x4v o = {s0[0], s1[0], s0[1], s1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, pb + 32 * ct + osp, 0, 0);
+            } else {
+                const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, pb + 64 * ct + of32, 0, 0);
+            }
+        }
+    }
+}
+
+#define WT_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory")
+#define WT_PIECE_LOADS(k_) ((k_) > 5 ? 0 : (k_) * WT_PIECE >= WT_XU ? 0 : ((k_) + 1) * WT_PIECE <= WT_XU ? WT_PIECE : WT_XU - (k_) * WT_PIECE)
+
+__global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int nitems) {
+    // ONE LDS array: the input tile, then the three weight buffers
+    __shared__ __attribute__((aligned(16))) float lds[WT_XIN + WT_NBUF * H3_TAP16 * 4];
+    float* const xin = lds;
+    f32x4 (*const wbuf)[H3_TAP16] = reinterpret_cast<f32x4 (*)[H3_TAP16]>(lds + WT_XIN);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // an ITEM is (tile, block cb of 64 output channels); item = tile * NC + cb, gridDim.x a multiple of NC: a workgroup keeps its cb, its
+    // weight stream -- [cb][chunk][tap] blocks of 16 KiB -- is periodic in 9 NC taps (kernels_conv_f16x3.hip)
+    const int NC = a.C >> 6, pix = a.C * 4, period = 9 * NC;
+    int item = blockIdx.x;
+    if (item >= nitems) return;                                  // (uniform over the workgroup)
+    const int cb = item % NC;
+    const bool in_split = (a.fmt & CV_FMT_X) != 0;
+
+    // BARRIER PLAN -- identical for the eight waves: per chunk of 64 input channels nine barriers B_tap, one in front of every tap,
+    // and one barrier E behind the last tap.  At B_T (global tap counter T): the weights of taps T and T + 1 have landed in buffers T % 3,
+    // (T + 1) % 3 (each helper waited for its own DMAs before arriving); every compute wave is done with tap T - 1, so buffer (T + 2) % 3 may
+    // be overwritten; at B_0 of a chunk the input tile is in place.  At E every compute wave is done with the input tile.
+    if (wv >= 4) {
+        // ------------------------------------------------ HELPER waves ------------------------------------------------
+        const int h = tid - WT_HTHREADS, hw = wv - 4;
+        WStaging st;
+        wstaging_init(a, h, st, pix);
+        f32x4 xpre[WT_XU];
+        {
+            const WFetch f0 = wfetch_begin(a, wtile_pos(a, item / NC), h, pix, 0);
+            wfetch_piece<0, WT_XU>(f0, st, xpre);
+        }
+        // a tap's weights: global memory -> LDS by LDS-DMA (`buffer_load_dwordx4 ... offen lds`, the tap in the SCALAR offset): helper wave w
+        // copies units w * 64 + lane + 256 j of the 1024
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 9 * a.C * a.C * 4, 0x00020000);
+        const int wvoff = h * 16, wbase = cb * period * (H3_TAP16 * 16);
+#define WT_DMA(buf_, t_)                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(&wbuf[buf_][hw * 64 + 256 * j]), 16, wvoff, \
+                                                     wbase + (t_) * (H3_TAP16 * 16) + j * 4096, 0, 0);
+        int t2 = 0;                                              // stream position of the NEXT tap to request
+        WT_DMA(0, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
+        WT_DMA(1, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
+        wput_input(xin, h, xpre, in_split);
+        WT_WAIT_VM(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // raw barriers: this wave's LDS writes are done before it arrives
+#pragma unroll 1
+        for (; item < nitems; item += gridDim.x) {
+            const WTilePos q = wtile_pos(a, item / NC);
+#pragma unroll 1
+            for (int cc = 0; cc < NC; ++cc) {
+                // the input tile that follows this one: the tile's next 64 input channels, or the first 64 of the next item
+                const bool last = cc + 1 == NC;
+                const bool more = !last || item + (int)gridDim.x < nitems;
+                const WFetch nx = wfetch_begin(a, last && more ? wtile_pos(a, (item + gridDim.x) / NC) : q, h, pix, last ? 0 : 64 * (cc + 1), more);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    __builtin_amdgcn_s_barrier();                 // B_tap
+                    asm volatile("" ::: "memory");
+                    WT_DMA((tap + 2) % 3, t2)                     // the weights of tap T + 2 into the buffer tap T - 1 has left
+                    t2 = t2 + 1 == period ? 0 : t2 + 1;
+                    // the counted wait below is right only if the four DMAs are OLDER than the piece: pin the order (tools/isa_scan.py checks it)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap == 0) wfetch_piece<0 * WT_PIECE, 1 * WT_PIECE>(nx, st, xpre);
+                    if (tap == 1) wfetch_piece<1 * WT_PIECE, 2 * WT_PIECE>(nx, st, xpre);
+                    if (tap == 2) wfetch_piece<2 * WT_PIECE, 3 * WT_PIECE>(nx, st, xpre);
+                    if (tap == 3) wfetch_piece<3 * WT_PIECE, 4 * WT_PIECE>(nx, st, xpre);
+                    if (tap == 4) wfetch_piece<4 * WT_PIECE, 5 * WT_PIECE>(nx, st, xpre);
+                    if (tap == 5) wfetch_piece<5 * WT_PIECE, 6 * WT_PIECE>(nx, st, xpre);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // everything but this tap's four DMAs and its piece has completed: the weights of tap T + 1 (requested one tap ago) and the
+                    // piece behind them are in place when this wave arrives at the next barrier
+                    if (tap == 0) { WT_WAIT_VM(4 + WT_PIECE_LOADS(0)); }
+                    if (tap == 1) { WT_WAIT_VM(4 + WT_PIECE_LOADS(1)); }
+                    if (tap == 2) { WT_WAIT_VM(4 + WT_PIECE_LOADS(2)); }
+                    if (tap == 3) { WT_WAIT_VM(4 + WT_PIECE_LOADS(3)); }
+                    if (tap == 4) { WT_WAIT_VM(4 + WT_PIECE_LOADS(4)); }
+                    if (tap == 5) { WT_WAIT_VM(4 + WT_PIECE_LOADS(5)); }
+                    if (tap >= 6) { WT_WAIT_VM(4); }
+                }
+                __builtin_amdgcn_s_barrier();                     // E: the compute waves are done with the input tile
+                asm volatile("" ::: "memory");
+                // (every piece is older than the DMAs of taps 6..8, which the waits above retired up to the last four: xpre is complete)
+                if (more) wput_input(xin, h, xpre, in_split);     // published by B_0 of the next chunk
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        // no wave ends with an LDS-DMA in flight (its LDS may belong to the next workgroup by the time the data lands)
+        WT_WAIT_VM(0);
+#undef WT_DMA
+        return;
+    }
+
+    // ------------------------------------------------ COMPUTE waves ------------------------------------------------
+    // v_mfma_f32_16x16x32_f16, D = A B with A = the weights (row = output channel) and B = the pixels (column = pixel): lane (i, kb)
+    // supplies A[channel i][k = 8 kb ..] and B[k = 8 kb ..][pixel i]; the wave's 64 pixels are four N tiles = its four tile rows (i =
+    // the pixel's column through h3_row_pixel), its 64 output channels four M tiles.  Accumulator reg r of lane (i, kb), tile (ct, pt) =
+    // channel 16 ct + 4 kb + r of pixel (tile row 4 w + pt, column h3_row_pixel(i)).
+    const int i = lane & 15, kb = lane >> 4;
+    const char* const a0 = reinterpret_cast<const char*>(xin) + (4 * wv * WT_HX + h3_row_pixel(i)) * WT_PSB + h3_chunk_pos(kb, 0, 0);
+    const char* const b0 = reinterpret_cast<const char*>(&wbuf[0][0]) + lane * 16;
+#pragma unroll 1
+    for (; item < nitems; item += gridDim.x) {
+        const WTilePos q = wtile_pos(a, item / NC);
+        f32x4 mainv[4][4], corrv[4][4];                            // [M tile ct = 16 output channels][N tile pt = tile row of the wave]
+        auto chunk = [&](const int cc, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            h8 xh[4], xl[4];                                       // pixel fragments of the current K step: [pt]
+            h8 wh[2][2], wl[2][2];                                 // weight fragments: [slot][ct of the pair]
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            // pixel fragment (tap, K step s2, tile row pt): + 32 s2: K step, + 16: the lo halves (f16x3_common.h)
+#define WT_LOAD_X(pt_, ap_, s2_)                                                                         \
+            xh[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_));       \
+            xl[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_) + 16);
+            // weight fragments of (buffer, K step s2, channel-tile pair cp): fragment f = (s2 * 4 + ct) * 2 + part, 1 KiB each
+#define WT_LOAD_W(slot_, buf_, s2_, cp_)                                                                 \
+            _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                           \
+                wh[slot_][c_] = *reinterpret_cast<const h8*>(b0 + (buf_) * (H3_TAP16 * 16) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2)));      \
+                wl[slot_][c_] = *reinterpret_cast<const h8*>(b0 + (buf_) * (H3_TAP16 * 16) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2) + 1));  \
+            }
+            // the six MFMAs of (pixel tile pt) x (channel-tile pair cp): main += w_hi x_hi; corr += w_lo x_hi; corr += w_hi x_lo -- the order
+            // of the narrow kernel (x_hi w_hi; x_hi w_lo; x_lo w_hi), the two dependent corr updates two instructions apart
+#define WT_MFMA6(slot_, cp_, pt_, z_)                                                                    \
+            {                                                                                            \
+                const int c0_ = 2 * (cp_), c1_ = 2 * (cp_) + 1;                                          \
+                mainv[c0_][pt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot_][0], xh[pt_], (z_) ? zero4 : mainv[c0_][pt_], 0, 0, 0);  \
+                corrv[c0_][pt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot_][0], xh[pt_], (z_) ? zero4 : corrv[c0_][pt_], 0, 0, 0);  \
+                mainv[c1_][pt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot_][1], xh[pt_], (z_) ? zero4 : mainv[c1_][pt_], 0, 0, 0);  \
+                corrv[c1_][pt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot_][1], xh[pt_], (z_) ? zero4 : corrv[c1_][pt_], 0, 0, 0);  \
+                corrv[c0_][pt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot_][0], xl[pt_], corrv[c0_][pt_], 0, 0, 0);                \
+                corrv[c1_][pt_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot_][1], xl[pt_], corrv[c1_][pt_], 0, 0, 0);                \
+            }
+#define WT_FENCE __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky, buf = tap % 3;
+                const char* const ap = a0 + (ky * WT_HX + kx) * WT_PSB;           // input pixel of this tap
+                const bool z = FIRST && tap == 0;                               // compile-time: the accumulators' first use (K step 0 only)
+                if (tap == 0) {
+                    // a new input tile: nothing of it may be read before B_0 (the weights of this tap landed long ago, but keep it simple)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    WT_LOAD_X(0, ap, 0) WT_LOAD_X(1, ap, 0) WT_LOAD_X(2, ap, 0) WT_LOAD_X(3, ap, 0)
+                    WT_LOAD_W(0, buf, 0, 0)
+                } else {
+                    // its first fragments were requested during the tap before (weights T + 1 are in place since B_T): only the barrier
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                WT_FENCE
+                // half step 0: K step 0, channel tiles 0, 1
+                WT_LOAD_W(1, buf, 0, 1)
+                WT_FENCE
+                WT_MFMA6(0, 0, 0, z) WT_MFMA6(0, 0, 1, z) WT_MFMA6(0, 0, 2, z) WT_MFMA6(0, 0, 3, z)
+                WT_FENCE
+                // half step 1: K step 0, channel tiles 2, 3 -- a pixel fragment is dead after its six MFMAs: K step 1's takes its registers
+                WT_LOAD_W(0, buf, 1, 0)
+                WT_FENCE
+                WT_MFMA6(1, 1, 0, z) WT_FENCE WT_LOAD_X(0, ap, 1) WT_FENCE
+                WT_MFMA6(1, 1, 1, z) WT_FENCE WT_LOAD_X(1, ap, 1) WT_FENCE
+                WT_MFMA6(1, 1, 2, z) WT_FENCE WT_LOAD_X(2, ap, 1) WT_FENCE
+                WT_MFMA6(1, 1, 3, z) WT_FENCE WT_LOAD_X(3, ap, 1) WT_FENCE
+                // half step 2: K step 1, channel tiles 0, 1
+                WT_LOAD_W(1, buf, 1, 1)
+                WT_FENCE
+                WT_MFMA6(0, 0, 0, false) WT_MFMA6(0, 0, 1, false) WT_MFMA6(0, 0, 2, false) WT_MFMA6(0, 0, 3, false)
+                WT_FENCE
+                // half step 3: K step 1, channel tiles 2, 3; behind each pixel tile the fragment of the NEXT tap's K step 0
+                if (tap + 1 < 9) {
+                    const int ky1 = (tap + 1) / 3, kx1 = tap + 1 - 3 * ky1;
+                    const char* const ap1 = a0 + (ky1 * WT_HX + kx1) * WT_PSB;
+                    WT_LOAD_W(0, (tap + 1) % 3, 0, 0)
+                    WT_FENCE
+                    WT_MFMA6(1, 1, 0, false) WT_FENCE WT_LOAD_X(0, ap1, 0) WT_FENCE
+                    WT_MFMA6(1, 1, 1, false) WT_FENCE WT_LOAD_X(1, ap1, 0) WT_FENCE
+                    WT_MFMA6(1, 1, 2, false) WT_FENCE WT_LOAD_X(2, ap1, 0) WT_FENCE
+                    WT_MFMA6(1, 1, 3, false) WT_FENCE WT_LOAD_X(3, ap1, 0) WT_FENCE
+                } else {
+                    WT_MFMA6(1, 1, 0, false) WT_MFMA6(1, 1, 1, false) WT_MFMA6(1, 1, 2, false) WT_MFMA6(1, 1, 3, false)
+                    WT_FENCE
+                }
+            }
+#undef WT_LOAD_X
+#undef WT_LOAD_W
+#undef WT_MFMA6
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // E: this wave's reads of the input tile are back
+            asm volatile("" ::: "memory");
+            (void)cc;
+        };
+        chunk(0, std::true_type{});
+#pragma unroll 1
+        for (int cc = 1; cc < NC; ++cc) chunk(cc, std::false_type{});
+
+        // ---- epilogue, straight from the accumulators (wepilogue above), one instance per combination of formats ----
+        switch ((a.skip ? 1 : 0) | ((a.fmt & CV_FMT_SKIP) ? 2 : 0) | ((a.fmt & CV_FMT_Y) ? 4 : 0)) {
+            case 0: wepilogue<false, false, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;
+            case 1: wepilogue<true, false, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;
+            case 3: wepilogue<true, true, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;
+            case 4: case 6: wepilogue<false, false, true>(a, q, mainv, corrv, wv, lane, pix, cb); break;
+            case 5: wepilogue<true, false, true>(a, q, mainv, corrv, wv, lane, pix, cb); break;
+            case 7: wepilogue<true, true, true>(a, q, mainv, corrv, wv, lane, pix, cb); break;
+            default: wepilogue<false, false, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;      // (2: a skip format without a skip tensor)
+        }
+    }
+}
+
+hipError_t launch_conv3x3_f16x3_wide(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
+                                     int n, int C, int H, int W, int relu, int fmt) {
+    if (C < 64 || C > 1024 || (C & 63) || (fmt & ~(CV_FMT_X | CV_FMT_SKIP | CV_FMT_Y))) return hipErrorInvalidValue;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.skip = skip; a.y = y; a.n = n; a.H = H; a.W = W; a.relu = relu; a.C = C; a.fmt = fmt;
+    a.tiles_x = (W + WT_TX - 1) / WT_TX; a.tiles_y = (H + WT_TY - 1) / WT_TY;
+    const int NC = C >> 6;
+    const long long items = (long long)n * a.tiles_x * a.tiles_y * NC;
+    if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((long long)H * W * C * 4 > 0x7fffffffLL) return hipErrorInvalidValue;           // one image must fit a signed 32-bit buffer offset
+    const int cus = conv_compute_units();
+    if (cus <= 0) return hipGetLastError();
+    // persistent workgroups, ONE per compute unit, a multiple of NC of them (a workgroup keeps its block of output channels); every
+    // workgroup's loop ends: item < nitems, and all eight waves of a workgroup run the same trip counts (the barrier plan)
+    long long grid = cus;
+    grid -= grid % NC;
+    if (grid < NC) grid = NC;
+    if (items < grid) grid = items;                               // items = tiles * NC: a multiple of NC as well
+    hipLaunchKernelGGL(k_conv3x3_h3w, dim3((unsigned)grid), dim3(WT_THREADS), 0, s, a, (int)items);
+    return hipGetLastError();
+}
+
+}  // namespace pnp

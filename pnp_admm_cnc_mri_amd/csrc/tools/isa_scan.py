@@ -25,11 +25,14 @@ def kernels_of(text):
         if not m:
             i += 1
             continue
-        name, body = m.group(1), []
+        name, body, labels = m.group(1), [], {}
         i += 1
         while i < len(lines) and not lines[i].startswith('.Lfunc_end'):
             ln = lines[i].strip()
-            if ln and not ln.startswith((';', '.')) and not ln.endswith(':'):
+            ml = re.match(r'^(\.LBB\w+):', ln)
+            if ml:
+                labels[ml.group(1)] = len(body)                  # index of the first instruction behind the label
+            elif ln and not ln.startswith((';', '.')) and not ln.endswith(':'):
                 body.append(ln.split(';')[0].strip())
             i += 1
         info = {}
@@ -41,7 +44,7 @@ def kernels_of(text):
                 break
             i += 1
         if 'codeLenInByte' in info:
-            res[name] = {'body': body, 'info': info}
+            res[name] = {'body': body, 'info': info, 'labels': labels}
     return res
 
 
@@ -87,37 +90,53 @@ def store_hazards(body, window=2):
     return bad
 
 
-def dma_order_violations(body, group=4):
-    """LDS-DMA ordering of the f16x3 convolution kernels (kernels_conv_f16x3.hip): a tap's weights are written into LDS by
-    `buffer_load_dwordx4 ... lds` (D below) and published to the other waves by `s_waitcnt vmcnt(n)` + `s_barrier`, where n counts the
-    plain loads / stores (L) issued BEHIND the DMAs that may stay in flight.  That count is right only while every D of a group is
-    older than those L: vector-memory operations complete in order, so `vmcnt(n)` retires everything but the youngest n.  The walk
-    keeps the operations that may still be in flight (a wait truncates the list to its youngest n), calls a barrier CLEAN when no D is
-    among them, and reports (a) a new group of D issued although no clean barrier followed the group before it -- a buffer would be
-    overwritten, or read, with its DMA unfinished -- and (b) a kernel that ends (s_endpgm) with a D possibly in flight.  A plain access
-    that slips between or in front of a group's DMAs with a counted wait behind it leaves a D among the youngest n: the barrier is not
-    clean and (a) fires at the next group.  The walk is over the linear instruction order (loops are not followed)."""
-    bad, inflight, dirty, run = [], [], False, 0
-    for idx, ins in enumerate(body):
-        if ins.startswith(('buffer_load', 'buffer_store', 'global_load', 'global_store', 'flat_load', 'flat_store', 'buffer_atomic', 'global_atomic')):
+def dma_order_violations(body, group=4, ahead=0, labels=None):
+    """LDS-DMA ordering of the f16x3 convolution kernels (kernels_conv_f16x3.hip / kernels_conv_f16x3_wide.hip): a tap's weights
+    are written into LDS by `buffer_load_dwordx4 ... lds` (D below) and published to the other waves by `s_waitcnt vmcnt(n)` + `s_barrier`,
+    where n counts the operations issued BEHIND the DMAs that may stay in flight.  That count is right only while every D of a group
+    is older than those operations: vector-memory operations complete in order, so `vmcnt(n)` retires everything but the youngest n.
+    The walk keeps the operations that may still be in flight (a wait truncates the list to its youngest n); at a barrier the groups
+    whose D are all retired count as PUBLISHED.  `ahead` = how many groups may be in flight across a barrier: 0 for the narrow kernel
+    (double-buffered: a tap's group lands before the next barrier), 1 for the wide one (triple-buffered: the group requested in tap T is
+    waited for at the end of tap T + 1).  Reported: (a) group g issued while fewer than g - ahead groups are published -- a buffer would
+    be overwritten, or read, with its DMA unfinished; (b) a kernel that ends (s_endpgm) with a D possibly in flight.  A plain access that
+    slips between or in front of a group's DMAs with a counted wait behind it leaves a D among the youngest n: that group stays
+    unpublished and (a) fires.  `labels` ({label: index into body}, kernels_of): every BACKWARD branch is followed again (ahead + 1 more times) -- the loop
+    body is walked with the state the pass before left, so the hand-over from a loop's last group to its first is checked
+    too (round 5's walk was linear and never saw a back edge)."""
+    bad = []
+    st = {'inflight': [], 'run': 0, 'published': 0}
+
+    def step(idx, ins):
+        if ins.startswith(('buffer_load', 'buffer_store', 'global_load', 'global_store', 'flat_load', 'flat_store', 'buffer_atomic', 'global_atomic',
+                           'scratch_load', 'scratch_store')):
             d = ins.startswith('buffer_load') and ins.rstrip().endswith(' lds')
             if d:
-                if run % group == 0 and dirty:
-                    bad.append((idx, 'LDS-DMA group issued before the group before it was published by a clean barrier', ins))
-                run += 1
-                if run % group == 0:
-                    dirty = True
-            inflight.append('D' if d else 'L')
-            continue
+                if st['run'] % group == 0 and st['published'] < st['run'] // group - ahead:
+                    bad.append((idx, 'LDS-DMA group issued before the group %s it was published by a barrier' % ('before' if ahead == 0 else '%d before' % (ahead + 1)), ins))
+                st['run'] += 1
+            st['inflight'].append('D' if d else 'L')
+            return
         m = re.match(r's_waitcnt\b.*vmcnt\((\d+)\)', ins)
         if m:
             n = int(m.group(1))
-            inflight = inflight[len(inflight) - n:] if n else []
+            st['inflight'] = st['inflight'][len(st['inflight']) - n:] if n else []
         elif ins.startswith('s_barrier'):
-            if 'D' not in inflight:
-                dirty = False
-        elif ins.startswith('s_endpgm') and 'D' in inflight:
+            nd = st['inflight'].count('D')
+            st['published'] = max(st['published'], st['run'] // group - (nd + group - 1) // group)
+        elif ins.startswith('s_endpgm') and 'D' in st['inflight']:
             bad.append((idx, 'wave may end with an LDS-DMA in flight', ins))
+
+    for idx, ins in enumerate(body):
+        step(idx, ins)
+        mb = re.match(r's_c?branch\w*\s+(\.LBB\w+)', ins) if labels else None
+        if mb and labels.get(mb.group(1), idx + 1) <= idx:          # a back edge: once more through the loop body, same state
+            seen = len(bad)
+            for _ in range(ahead + 1):                               # (a stream that runs `ahead` groups ahead shows a miscount one pass later)
+                for k in range(labels[mb.group(1)], idx + 1):
+                    step(k, body[k])
+            for k in range(seen, len(bad)):
+                bad[k] = (bad[k][0], bad[k][1] + ' (second pass through the loop: the back edge)', bad[k][2])
     return bad
 
 
@@ -128,7 +147,8 @@ def scan_text(text):
         n += sum(1 for ins in k['body'] if re.match(r'buffer_store_dwordx[34]', ins))
         bad += [(name, a, b) for a, b in store_hazards(k['body'])]
         if '_h3' in name and any(ins.startswith('buffer_load') and ins.rstrip().endswith(' lds') for ins in k['body']):
-            bad += [(name, 'LDS-DMA order: ' + why, ins) for _, why, ins in dma_order_violations(k['body'])]
+            ahead = 1 if '_h3w' in name else 0                   # the wide kernel's weight stream runs one tap further ahead (three buffers)
+            bad += [(name, 'LDS-DMA order: ' + why, ins) for _, why, ins in dma_order_violations(k['body'], ahead=ahead, labels=k['labels'])]
     return bad, n
 
 

@@ -25,7 +25,7 @@ from conftest import ROOT
 CSRC = os.path.join(ROOT, 'pnp_admm_cnc_mri_amd', 'csrc')
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 SOURCES = ['kernels_slice256.hip', 'kernels_fused256.hip', 'kernels_fused512.hip', 'kernels_generic.hip', 'kernels_conv.hip', 'kernels_conv_f16x3.hip',
-           'kernels_pix2x2_f16x3.hip', 'api.hip']
+           'kernels_conv_f16x3_wide.hip', 'kernels_pix2x2_f16x3.hip', 'api.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off']     # = csrc/Makefile CXXFLAGS
 
 import importlib.util
@@ -39,7 +39,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not ins
 
 def _compile(args):
     src, out = args
-    extra = ['-fno-slp-vectorize'] if src in ('kernels_conv_f16x3.hip', 'kernels_pix2x2_f16x3.hip') else []          # = the Makefile's per-file flag
+    extra = ['-fno-slp-vectorize'] if src in ('kernels_conv_f16x3.hip', 'kernels_conv_f16x3_wide.hip', 'kernels_pix2x2_f16x3.hip') else []          # = the Makefile's per-file flag
     r = subprocess.run([HIPCC] + FLAGS + extra + ['--cuda-device-only', '-S', os.path.join(CSRC, src), '-o', out],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=CSRC)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -160,7 +160,41 @@ def test_f16x3_weight_dma_is_older_than_the_loads_counted_behind_it(asm):
     assert len(ks) == 4
     for n, k in ks.items():
         assert sum(1 for x in k['body'] if x.startswith('buffer_load') and x.rstrip().endswith(' lds')) >= 76, n
-        assert not dma_order_violations(k['body']), (n, dma_order_violations(k['body'])[:3])
+        assert not dma_order_violations(k['body'], labels=k['labels']), (n, dma_order_violations(k['body'], labels=k['labels'])[:3])
+    # round 6 (advisor): back edges -- the hand-over from a loop's last group to its first is walked too
+    loop = ['s_barrier'] + [D] * 4 + [L, L, 's_waitcnt vmcnt(2)', 's_cbranch_scc1 .LBB0_1']
+    assert not dma_order_violations([D] * 4 + ['s_waitcnt vmcnt(0)'] + loop + ['s_waitcnt vmcnt(0)', 's_endpgm'], labels={'.LBB0_1': 5})
+    bad_loop = ['s_barrier'] + [D] * 4 + [L, L, 's_waitcnt vmcnt(6)', 's_cbranch_scc1 .LBB0_1']      # the wait leaves the group in flight ...
+    assert not dma_order_violations([D] * 4 + ['s_waitcnt vmcnt(0)'] + bad_loop + ['s_waitcnt vmcnt(0)', 's_endpgm'])     # ... a linear walk misses it,
+    assert dma_order_violations([D] * 4 + ['s_waitcnt vmcnt(0)'] + bad_loop + ['s_waitcnt vmcnt(0)', 's_endpgm'], labels={'.LBB0_1': 5})   # the second pass does not
+    # ahead = 1 (the wide kernel: three buffers, the group requested in tap T is waited for at the end of tap T + 1)
+    wide = [D] * 8 + ['s_waitcnt vmcnt(0)'] + ['s_barrier'] + [D] * 4 + [L, 's_waitcnt vmcnt(5)', 's_cbranch_scc1 .LBB0_1'] + ['s_waitcnt vmcnt(0)', 's_endpgm']
+    assert not dma_order_violations(wide, ahead=1, labels={'.LBB0_1': 9})
+    assert dma_order_violations(wide, ahead=0, labels={'.LBB0_1': 9})                                   # the narrow kernel's rule forbids it
+    assert dma_order_violations([x.replace('vmcnt(5)', 'vmcnt(9)') for x in wide], ahead=1, labels={'.LBB0_1': 9})      # two groups in flight at a barrier
+
+
+def test_wide_f16x3_kernel_resources(asm):
+    """k_conv3x3_h3w (csrc/kernels_conv_f16x3_wide.hip): ONE workgroup of eight waves per compute unit (<= 256 registers, no scratch, 134 KiB
+    of LDS), 2 x 9 x 96 half-precision matrix instructions (two instances of the chunk code), inside the compute waves' tap loop nothing but
+    LDS reads, MFMAs, waits and barriers -- the point of the kernel --, and a weight stream whose counted waits hold on the compiled ISA
+    (three buffers: one group may be in flight across a barrier), back edges included."""
+    ks = {n: k for n, k in kernels_of(asm['kernels_conv_f16x3_wide.hip']).items() if 'k_conv3x3_h3w' in n}
+    assert len(ks) == 1, sorted(ks)
+    for n, k in ks.items():
+        i = k['info']
+        assert i['ScratchSize'] == 0 and i['NumVgprs'] + i['NumAgprs'] <= 256 and i['LDSByteSize'] == 137280, (n, i)
+        mf = [j for j, x in enumerate(k['body']) if x.startswith('v_mfma')]
+        assert len(mf) == 2 * 9 * 96 and all(k['body'][j].startswith('v_mfma_f32_16x16x32_f16') for j in mf), (n, len(mf))
+        assert sum(1 for j in mf if k['body'][j].split(';')[0].rstrip().endswith(', 0')) == 32, n        # 16 main + 16 correction accumulators start from 0
+        # between the first and the last MFMA of each chunk instance: ds_read_b128, MFMA, s_waitcnt, s_barrier (+ s_nop) only
+        for lo, hi in ((mf[0], mf[863]), (mf[864], mf[-1])):
+            other = [x for x in k['body'][lo:hi] if not x.startswith(('v_mfma', 'ds_read_b128', 's_waitcnt', 's_barrier', 's_nop'))]
+            assert not other, (n, other[:5])
+            assert sum(1 for x in k['body'][lo:hi] if x.startswith('ds_read_b128')) >= 9 * 32 - 16, n           # (tap 0's first twelve reads and its second weight pair stand in front of the first MFMA)
+        assert sum(1 for x in k['body'] if x.startswith('buffer_load') and x.rstrip().endswith(' lds')) == 8 + 36, n
+        assert not dma_order_violations(k['body'], ahead=1, labels=k['labels']), (n, dma_order_violations(k['body'], ahead=1, labels=k['labels'])[:3])
+        assert dma_order_violations(k['body'], ahead=0, labels=k['labels'])                          # (the scan does tell the two protocols apart)
 
 
 def test_pix2x2_kernel_resources(asm):
@@ -176,7 +210,7 @@ def test_pix2x2_kernel_resources(asm):
         mf = [x for x in k['body'] if x.startswith('v_mfma')]
         assert len(mf) == 96 and all(x.startswith('v_mfma_f32_16x16x32_f16') for x in mf), (n, len(mf))
         assert sum(1 for x in k['body'] if x.startswith('buffer_load') and x.rstrip().endswith(' lds')) == 12, n
-        assert not dma_order_violations(k['body']), (n, dma_order_violations(k['body'])[:3])
+        assert not dma_order_violations(k['body'], labels=k['labels']), (n, dma_order_violations(k['body'], labels=k['labels'])[:3])
 
 
 def test_hazard_scanner_sees_the_pattern_that_bit_us():
