@@ -11,14 +11,16 @@
 //     nothing else --, waves 4-7 (one beside each compute wave on its SIMD) are HELPERS: they issue every LDS-DMA of the weight stream, fetch
 //     the next input tile into registers piece by piece, split it and write it into LDS between two chunks, and count the waits; what
 //     they do overlaps the partner's MFMAs instead of interrupting them;
-//   * weights are TRIPLE-buffered: at the barrier that opens tap T the weights of taps T and T + 1 have landed, so a compute wave reads
-//     its first fragments of tap T + 1 before that tap's barrier -- after a barrier the next instruction is an MFMA;
+//   * weights in FOUR buffers, three taps ahead: at the barrier that opens tap T the weights of taps T and T + 1 have landed, so a compute
+//     wave reads its first fragments of tap T + 1 before that tap's barrier -- after a barrier the next instruction is an MFMA;
 //   * the matrix product is taken TRANSPOSED (A = weights: M = output channels, B = pixels): an accumulator quad of a lane is then four
 //     consecutive channels of ONE pixel and leaves as a 16-byte store straight from the registers -- no LDS staging, no wave barrier, no
 //     second workgroup barrier per item.  For the split activation format two v_permlane16_swap per store pair the lane rows up so that
 //     each lane still stores 16 bytes (eight hi halves or eight lo halves).
 // The arithmetic is the narrow kernel's, instruction for instruction per output value (same products, same order of accumulation):
-// tests/test_gpu_conv.py holds the two kernels BIT-equal.  16 x 16 pixel tiles: 88 KiB of input tile + 48 KiB of weights in LDS.
+// tests/test_gpu_conv.py holds the two kernels BIT-equal.  16 x 16 pixel tiles: 86 KiB of input tile + 64 KiB of weights in LDS.
+// Measured (profiles/conv_f16x3_wide_r06.txt): 3.39e6 cycles per [640, 64, 128, 128] launch against the narrow kernel's 3.99e6, matrix pipe busy 0.65
+// against 0.55; per item of 13.8 k MFMA cycles the taps take 15.4 k, the epilogue 4.6 k, the barriers 1.2 k.
 #include "conv_common.h"
 #include "f16x3_common.h"
 #include <type_traits>
@@ -29,10 +31,10 @@ constexpr int WT_TX = 16, WT_TY = 16;                            // output tile
 constexpr int WT_HX = WT_TX + 2, WT_HY = WT_TY + 2;              // with halo
 constexpr int WT_PSB = CV_PS * 4;                                // bytes between consecutive pixels of the LDS tile (272)
 constexpr int WT_XIN = WT_HY * WT_HX * CV_PS;                    // floats of the input tile (88 128 bytes)
-constexpr int WT_HTHREADS = 256;                                 // helper threads
+constexpr int WT_HTHREADS = 256;                                 // threads of the four HELPER waves (4..7)
 constexpr int WT_XU = (WT_HY * WT_HX * 16 + WT_HTHREADS - 1) / WT_HTHREADS;     // 16-byte chunks of the tile per helper thread: 21
 constexpr int WT_THREADS = 512;
-constexpr int WT_NBUF = 3;                                       // weight buffers (a chunk has 9 taps: buffer of tap t = t % 3, a constant)
+constexpr int WT_NBUF = 4;                                       // weight buffers: the stream runs three taps ahead of the MFMAs (buffer of global tap T = T % 4)
 constexpr int WT_PIECE = (WT_XU + 5) / 6;                        // the next input tile is requested in six pieces, behind the DMAs of taps 0..5
 
 struct WTilePos { int img, y0, x0; };
@@ -45,17 +47,14 @@ __device__ __forceinline__ WTilePos wtile_pos(const ConvArgs& a, int t) {
     return q;
 }
 
-// ---- helper side: input staging (the narrow kernel's scheme, kernels_conv_f16x3.hip, on the 18 x 18 tile and 256 helper threads) ----
-// chunk u of helper thread h is tile pixel p = stage_pixel(h) + 16 u = (row r, column c), channels 4 (h & 15) ..; pk[u] = (r W + c) * pix | c, or -1
-__device__ __forceinline__ int wstage_pixel(int h) { const int g = h >> 4; return (g >> 1) + 8 * (g & 1); }
-struct WStaging { int pk[WT_XU]; };
-__device__ __forceinline__ void wstaging_init(const ConvArgs& a, int h, WStaging& st, const int pix) {
-#pragma unroll
-    for (int u = 0; u < WT_XU; ++u) {
-        const int p = wstage_pixel(h) + 16 * u, r = p / WT_HX, c = p - r * WT_HX;
-        st.pk[u] = (p < WT_HY * WT_HX) ? (((r * a.W + c) * pix) | c) : -1;
-    }
-}
+// ---- helper waves: input staging (the narrow kernel's scheme, kernels_conv_f16x3.hip, on the 18 x 18 tile and 256 threads) ----
+// chunk u of helper thread h (0..255) is tile pixel p = wstage_pixel(h, u) = (row r, column c), channels 4 (h & 15) ..  Sixteen 16-lane groups:
+// the two groups of a 32-lane half take pixels 8 apart (8 x 272 bytes = 32 banks: their 8-byte LDS writes do not collide).
+__device__ __forceinline__ constexpr int wstage_pixel(int h, int u) { return ((h >> 4) >> 1) + 8 * ((h >> 4) & 1) + 16 * u; }
+// (the narrow kernel keeps one packed coordinate register per chunk; here the coordinates are recomputed per load -- a division by the
+// constant 18 is a multiplication, and a helper wave's vector instructions run beside its partner's MFMAs, not instead of them)
+struct WStaging { int h; int aW, pix; };
+__device__ __forceinline__ void wstaging_init(const ConvArgs& a, int h, WStaging& st, const int pix) { st.h = h; st.aW = a.W; st.pix = pix; }
 struct WFetch { __amdgpu_buffer_rsrc_t rs; int origin, xlo, xhi; };
 __device__ __forceinline__ WFetch wfetch_begin(const ConvArgs& a, const WTilePos& q, int h, const int pix, const int coff, const bool any = true) {
     WFetch f;
@@ -69,33 +68,34 @@ template <int U0, int U1>
 __device__ __forceinline__ void wfetch_piece(const WFetch& f, const WStaging& st, f32x4 (&v)[WT_XU]) {
 #pragma unroll
     for (int u = U0; u < U1 && u < WT_XU; ++u) {
-        const int c = st.pk[u] & 255;
-        const bool in = st.pk[u] >= 0 && c >= f.xlo && c < f.xhi;
-        const int off = in ? f.origin + (st.pk[u] & ~255) : -16;
+        const int p = wstage_pixel(st.h, u), r = p / WT_HX, c = p - r * WT_HX;
+        const bool in = p < WT_HY * WT_HX && c >= f.xlo && c < f.xhi;
+        const int off = in ? f.origin + (r * st.aW + c) * st.pix : -16;
         const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(f.rs, off, 0, 0);
         v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
     }
 }
 // registers -> LDS tile (split on the way unless the tensor is in the SPLIT activation format already): put_input_h3's layout
+template <int U0 = 0, int U1 = WT_XU>
 __device__ __forceinline__ void wput_input(float* xin, int h, const f32x4 (&v)[WT_XU], const bool in_split) {
     if (in_split) {
         const int q = h & 15;
-        char* px = reinterpret_cast<char*>(xin) + wstage_pixel(h) * WT_PSB + h3_chunk_pos(q & 3, (q >> 2) & 1, q >> 3);
+        char* px = reinterpret_cast<char*>(xin) + wstage_pixel(h, 0) * WT_PSB + h3_chunk_pos(q & 3, (q >> 2) & 1, q >> 3);
 #pragma unroll
-        for (int u = 0; u < WT_XU; ++u)
-            if (wstage_pixel(h) + 16 * u < WT_HY * WT_HX)
-                *reinterpret_cast<f32x4*>(px + u * (16 * WT_PSB)) = v[u];
+        for (int u = U0; u < U1; ++u)
+            if (wstage_pixel(h, u) < WT_HY * WT_HX)
+                *reinterpret_cast<f32x4*>(px + (wstage_pixel(0, u)) * WT_PSB) = v[u];
         return;
     }
     const int t = h & 15;
-    char* px = reinterpret_cast<char*>(xin) + wstage_pixel(h) * WT_PSB + h3_chunk_pos((t >> 1) & 3, t >> 3, 0) + 8 * (t & 1);
+    char* px = reinterpret_cast<char*>(xin) + wstage_pixel(h, 0) * WT_PSB + h3_chunk_pos((t >> 1) & 3, t >> 3, 0) + 8 * (t & 1);
 #pragma unroll
-    for (int u = 0; u < WT_XU; ++u)
-        if (wstage_pixel(h) + 16 * u < WT_HY * WT_HX) {
+    for (int u = U0; u < U1; ++u)
+        if (wstage_pixel(h, u) < WT_HY * WT_HX) {
             h4 hi, lo;
             split4(v[u], hi, lo);
-            *reinterpret_cast<h4*>(px + u * (16 * WT_PSB)) = hi;
-            *reinterpret_cast<h4*>(px + u * (16 * WT_PSB) + 16) = lo;
+            *reinterpret_cast<h4*>(px + (wstage_pixel(0, u)) * WT_PSB) = hi;
+            *reinterpret_cast<h4*>(px + (wstage_pixel(0, u)) * WT_PSB + 16) = lo;
         }
 }
 
@@ -107,7 +107,7 @@ __device__ __forceinline__ void wput_input(float* xin, int h, const f32x4 (&v)[W
 // tensor (acc + bias) + skip.
 template <bool SKIP, bool KSPLIT, bool YSPLIT>
 __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, const f32x4 (&mainv)[4][4], const f32x4 (&corrv)[4][4],
-                                          int wv, int lane, const int pix, const int cb) {
+                                          int wv, int lane, const int pix, const int cb, const float* lbias) {
     typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, 64 * cb);
     const __amdgpu_buffer_rsrc_t rk = image_rsrc((SKIP ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, 64 * cb);
@@ -123,22 +123,22 @@ __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, 
     const int of32 = 16 * kb, osp = 16 * (kb >> 1) + 128 * (kb & 1);
     // ReLU without a branch: v < thr ? 0 : v with thr = 0, or -inf (never true; NaN stays NaN either way: torch.nn.ReLU)
     const float thr = a.relu ? 0.f : -__builtin_inff();
-    f32x4 bs[4];
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias ? a.bias : a.w), 0, a.bias ? a.C * 4 : 0, 0x00020000);
+    // byte offset of this lane's pixel in tile row pt; rows below the image: beyond the buffer's range by themselves; columns right of
+    // it: such an offset
+    const int pb0 = gx < a.W ? ((q.y0 + 4 * wv) * a.W + gx) * pix : -256, pbs = gx < a.W ? a.W * pix : 0;
+#define WT_PB(pt_) (pb0 + (pt_) * pbs)
+    f32x4 bs[4];                                                 // this lane's four channels per channel tile: from LDS (the helpers put them there)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {                             // (no bias: a descriptor of zero bytes returns zeros)
-        const u32x4v b = __builtin_amdgcn_raw_buffer_load_b128(rb, (64 * cb + 16 * ct) * 4 + 16 * kb, 0, 0);
-        bs[ct] = f32x4{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
-    }
+    for (int ct = 0; ct < 4; ++ct) bs[ct] = *reinterpret_cast<const f32x4*>(lbias + 16 * ct + 4 * kb);
+    u32x4v kq[SKIP ? 4 : 1][4];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
-        // rows below the image: beyond the buffer's range by themselves; columns right of it: such an offset
-        const int pb = gx < a.W ? ((q.y0 + 4 * wv + pt) * a.W + gx) * pix : -256;
-        u32x4v kq[4];
-        if (SKIP) {                                              // the four requests of a tile row first: one memory round trip
+        if (SKIP && !(pt & 1)) {                                 // the eight requests of two tile rows at once: two memory round trips per item
+#pragma unroll                                                   // (all sixteen at once: 64 registers more than the accumulators leave)
+            for (int p2 = pt; p2 < pt + 2; ++p2)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-                kq[ct] = __builtin_amdgcn_raw_buffer_load_b128(rk, pb + (KSPLIT ? 32 * ct + osp : 64 * ct + of32), 0, 0);
+                for (int ct = 0; ct < 4; ++ct)
+                    kq[p2][ct] = __builtin_amdgcn_raw_buffer_load_b128(rk, WT_PB(p2) + (KSPLIT ? 32 * ct + osp : 64 * ct + of32), 0, 0);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
@@ -150,17 +150,17 @@ __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, 
                 if (SKIP) {
                     if (KSPLIT) {
                         // undo the producer's lane-row exchange: afterwards hq = this lane's four hi halves, lq its four lo halves
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(kq[ct].x, kq[ct].z, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(kq[ct].y, kq[ct].w, false, false);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(kq[SKIP ? pt : 0][ct].x, kq[SKIP ? pt : 0][ct].z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(kq[SKIP ? pt : 0][ct].y, kq[SKIP ? pt : 0][ct].w, false, false);
                         const h4 hq = __builtin_bit_cast(h4, u32x2v{s0[0], s1[0]}), lq = __builtin_bit_cast(h4, u32x2v{s0[1], s1[1]});
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += unsplit(hq[r], lq[r]);
                     } else {
-                        v += f32x4{__uint_as_float(kq[ct].x), __uint_as_float(kq[ct].y), __uint_as_float(kq[ct].z), __uint_as_float(kq[ct].w)};
+                        { const u32x4v k_ = kq[SKIP ? pt : 0][ct]; v += f32x4{__uint_as_float(k_.x), __uint_as_float(k_.y), __uint_as_float(k_.z), __uint_as_float(k_.w)}; }
                     }
                 }
             } else if (SKIP) {
-                v += f32x4{__uint_as_float(kq[ct].x), __uint_as_float(kq[ct].y), __uint_as_float(kq[ct].z), __uint_as_float(kq[ct].w)} + bs[ct];
+                { const u32x4v k_ = kq[SKIP ? pt : 0][ct]; v += f32x4{__uint_as_float(k_.x), __uint_as_float(k_.y), __uint_as_float(k_.z), __uint_as_float(k_.w)} + bs[ct]; }
             } else {
                 v += bs[ct];
             }
@@ -175,22 +175,35 @@ __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, 
                 const auto s0 = __builtin_amdgcn_permlane16_swap(hu.x, lu.x, false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(hu.y, lu.y, false, false);
                 const u32x4v o = {s0[0], s1[0], s0[1], s1[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ry, pb + 32 * ct + osp, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, WT_PB(pt) + 32 * ct + osp, 0, 0);
             } else {
                 const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ry, pb + 64 * ct + of32, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, WT_PB(pt) + 64 * ct + of32, 0, 0);
             }
         }
     }
+#undef WT_PB
 }
 
 #define WT_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory")
 #define WT_PIECE_LOADS(k_) ((k_) > 5 ? 0 : (k_) * WT_PIECE >= WT_XU ? 0 : ((k_) + 1) * WT_PIECE <= WT_XU ? WT_PIECE : WT_XU - (k_) * WT_PIECE)
 
+#ifdef H3W_PROF
+// diagnostic build (profiles/variants.sh build kernels_conv_f16x3_wide.hip h3wprof "-DH3W_PROF"): shader-clock sums per phase, compute wave 0 of every
+// workgroup.  The stamp (cdna_hip_programming.md section 7): s_memtime + lgkmcnt(0) as ONE statement -- it drains the LDS reads the tap loop keeps in
+// flight across a barrier, so the instrumented build is a little slower than the real one (stamps sit at barriers only).
+__device__ unsigned g_h3wprof[1024 * 8];
+#define WT_STAMP(k) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); psum[k] += (unsigned)(t_ - tlast); tlast = t_; }
+#else
+#define WT_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int nitems) {
     // ONE LDS array: the input tile, then the three weight buffers
-    __shared__ __attribute__((aligned(16))) float lds[WT_XIN + WT_NBUF * H3_TAP16 * 4];
+    __shared__ __attribute__((aligned(16))) float lds[WT_XIN + WT_NBUF * H3_TAP16 * 4 + 64];
     float* const xin = lds;
+    float* const lbias = lds + WT_XIN + WT_NBUF * H3_TAP16 * 4;   // the 64 biases of this workgroup's block of output channels (its cb never changes)
     f32x4 (*const wbuf)[H3_TAP16] = reinterpret_cast<f32x4 (*)[H3_TAP16]>(lds + WT_XIN);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,11 +216,11 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
     const bool in_split = (a.fmt & CV_FMT_X) != 0;
 
     // BARRIER PLAN -- identical for the eight waves: per chunk of 64 input channels nine barriers B_tap, one in front of every tap,
-    // and one barrier E behind the last tap.  At B_T (global tap counter T): the weights of taps T and T + 1 have landed in buffers T % 3,
-    // (T + 1) % 3 (each helper waited for its own DMAs before arriving); every compute wave is done with tap T - 1, so buffer (T + 2) % 3 may
+    // and one barrier E behind the last tap.  At B_T (global tap counter T): the weights of taps T and T + 1 have landed in buffers T % 4,
+    // (T + 1) % 4 (each helper waited for its own DMAs before arriving); every compute wave is done with tap T - 1, so buffer (T + 3) % 4 may
     // be overwritten; at B_0 of a chunk the input tile is in place.  At E every compute wave is done with the input tile.
     if (wv >= 4) {
-        // ------------------------------------------------ HELPER waves ------------------------------------------------
+        // ------------------------------------------------ HELPER waves (4..7) ------------------------------------------------
         const int h = tid - WT_HTHREADS, hw = wv - 4;
         WStaging st;
         wstaging_init(a, h, st, pix);
@@ -216,18 +229,31 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
             const WFetch f0 = wfetch_begin(a, wtile_pos(a, item / NC), h, pix, 0);
             wfetch_piece<0, WT_XU>(f0, st, xpre);
         }
-        // a tap's weights: global memory -> LDS by LDS-DMA (`buffer_load_dwordx4 ... offen lds`, the tap in the SCALAR offset): helper wave w
-        // copies units w * 64 + lane + 256 j of the 1024
+        // A tap's 16 KiB of weights: global memory -> LDS by LDS-DMA (`buffer_load_dwordx4 ... offen lds`, the tap in the SCALAR offset): helper
+        // wave w copies units w * 64 + lane + 256 j of the 1024.  FOUR buffers, global tap T in buffer T % 4: in tap T the block of tap T + 3
+        // is requested into the buffer tap T - 1 has left, and the wait at the end of tap T leaves that request (and the input piece behind
+        // it) in flight -- what it retires is the block of tap T + 2, requested a whole tap earlier.  At B_(T+1) the weights of taps T + 1 and
+        // T + 2 are in place: the compute waves may read tap T + 2's first fragments before B_(T+2).  (Three buffers with the wait one group
+        // later -- this kernel's first version -- let that read race the DMA; three buffers with the wait in the requesting tap put a DMA's
+        // latency on the barrier: profiles/conv_f16x3_wide_r06.txt.)
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 9 * a.C * a.C * 4, 0x00020000);
         const int wvoff = h * 16, wbase = cb * period * (H3_TAP16 * 16);
-#define WT_DMA(buf_, t_)                                                                                                      \
+        f32x4* const wb0 = &wbuf[0][hw * 64];
+#define WT_DMA(rot_, t_)                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(&wbuf[buf_][hw * 64 + 256 * j]), 16, wvoff, \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(wb0 + (rot_) * H3_TAP16 + 256 * j), 16, wvoff, \
                                                      wbase + (t_) * (H3_TAP16 * 16) + j * 4096, 0, 0);
         int t2 = 0;                                              // stream position of the NEXT tap to request
         WT_DMA(0, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
         WT_DMA(1, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
+        WT_DMA(2, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
+        int rot = 3;                                             // buffer of the next request = (global tap + 3) % 4
         wput_input(xin, h, xpre, in_split);
+        {   // the biases, read by the compute waves' epilogues from LDS instead of a memory round trip per item (no bias: a descriptor of zero bytes returns zeros)
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias ? a.bias : a.w), 0, a.bias ? a.C * 4 : 0, 0x00020000);
+            const float bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (64 * cb + (h & 63)) * 4, 0, 0));
+            if (h < 64) lbias[h] = bv;
+        }
         WT_WAIT_VM(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // raw barriers: this wave's LDS writes are done before it arrives
 #pragma unroll 1
@@ -243,8 +269,9 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
                 for (int tap = 0; tap < 9; ++tap) {
                     __builtin_amdgcn_s_barrier();                 // B_tap
                     asm volatile("" ::: "memory");
-                    WT_DMA((tap + 2) % 3, t2)                     // the weights of tap T + 2 into the buffer tap T - 1 has left
+                    WT_DMA(rot, t2)                               // the weights of tap T + 3 into the buffer tap T - 1 has left
                     t2 = t2 + 1 == period ? 0 : t2 + 1;
+                    rot = (rot + 1) & 3;
                     // the counted wait below is right only if the four DMAs are OLDER than the piece: pin the order (tools/isa_scan.py checks it)
                     __builtin_amdgcn_sched_barrier(0);
                     if (tap == 0) wfetch_piece<0 * WT_PIECE, 1 * WT_PIECE>(nx, st, xpre);
@@ -254,8 +281,7 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
                     if (tap == 4) wfetch_piece<4 * WT_PIECE, 5 * WT_PIECE>(nx, st, xpre);
                     if (tap == 5) wfetch_piece<5 * WT_PIECE, 6 * WT_PIECE>(nx, st, xpre);
                     __builtin_amdgcn_sched_barrier(0);
-                    // everything but this tap's four DMAs and its piece has completed: the weights of tap T + 1 (requested one tap ago) and the
-                    // piece behind them are in place when this wave arrives at the next barrier
+                    // everything but this tap's four DMAs and its piece has completed
                     if (tap == 0) { WT_WAIT_VM(4 + WT_PIECE_LOADS(0)); }
                     if (tap == 1) { WT_WAIT_VM(4 + WT_PIECE_LOADS(1)); }
                     if (tap == 2) { WT_WAIT_VM(4 + WT_PIECE_LOADS(2)); }
@@ -285,6 +311,11 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
     const int i = lane & 15, kb = lane >> 4;
     const char* const a0 = reinterpret_cast<const char*>(xin) + (4 * wv * WT_HX + h3_row_pixel(i)) * WT_PSB + h3_chunk_pos(kb, 0, 0);
     const char* const b0 = reinterpret_cast<const char*>(&wbuf[0][0]) + lane * 16;
+    int rot = 0;                                                 // buffer of the current tap = global tap % 4 (uniform)
+#ifdef H3W_PROF
+    unsigned psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
     for (; item < nitems; item += gridDim.x) {
         const WTilePos q = wtile_pos(a, item / NC);
@@ -299,10 +330,10 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
             xh[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_));       \
             xl[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_) + 16);
             // weight fragments of (buffer, K step s2, channel-tile pair cp): fragment f = (s2 * 4 + ct) * 2 + part, 1 KiB each
-#define WT_LOAD_W(slot_, buf_, s2_, cp_)                                                                 \
+#define WT_LOAD_W(slot_, bw_, s2_, cp_)                                                                  \
             _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                           \
-                wh[slot_][c_] = *reinterpret_cast<const h8*>(b0 + (buf_) * (H3_TAP16 * 16) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2)));      \
-                wl[slot_][c_] = *reinterpret_cast<const h8*>(b0 + (buf_) * (H3_TAP16 * 16) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2) + 1));  \
+                wh[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2)));      \
+                wl[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2) + 1));  \
             }
             // the six MFMAs of (pixel tile pt) x (channel-tile pair cp): main += w_hi x_hi; corr += w_lo x_hi; corr += w_hi x_lo -- the order
             // of the narrow kernel (x_hi w_hi; x_hi w_lo; x_lo w_hi), the two dependent corr updates two instructions apart
@@ -319,36 +350,44 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
 #define WT_FENCE __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap - 3 * ky, buf = tap % 3;
+                const int ky = tap / 3, kx = tap - 3 * ky;
                 const char* const ap = a0 + (ky * WT_HX + kx) * WT_PSB;           // input pixel of this tap
+                // this tap's weight buffer and the next one's: ONE vector add per tap each (the buffer rotates through four, a chunk has nine taps)
+                const char* const bw = b0 + rot * (H3_TAP16 * 16);
+                const char* const bw1 = b0 + ((rot + 1) & 3) * (H3_TAP16 * 16);
+                rot = (rot + 1) & 3;
                 const bool z = FIRST && tap == 0;                               // compile-time: the accumulators' first use (K step 0 only)
                 if (tap == 0) {
                     // a new input tile: nothing of it may be read before B_0 (the weights of this tap landed long ago, but keep it simple)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    WT_STAMP(0)                                              // (0: what lies between two chunks besides the barriers: epilogue excluded)
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    WT_STAMP(1)                                              // 1: waiting at B_0 (the input waves' hand-over)
                     WT_LOAD_X(0, ap, 0) WT_LOAD_X(1, ap, 0) WT_LOAD_X(2, ap, 0) WT_LOAD_X(3, ap, 0)
-                    WT_LOAD_W(0, buf, 0, 0)
+                    WT_LOAD_W(0, bw, 0, 0)
                 } else {
                     // its first fragments were requested during the tap before (weights T + 1 are in place since B_T): only the barrier
+                    WT_STAMP(2)                                              // 2: the taps (LDS reads + MFMAs)
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    WT_STAMP(3)                                              // 3: waiting at B_1..8
                 }
                 WT_FENCE
                 // half step 0: K step 0, channel tiles 0, 1
-                WT_LOAD_W(1, buf, 0, 1)
+                WT_LOAD_W(1, bw, 0, 1)
                 WT_FENCE
                 WT_MFMA6(0, 0, 0, z) WT_MFMA6(0, 0, 1, z) WT_MFMA6(0, 0, 2, z) WT_MFMA6(0, 0, 3, z)
                 WT_FENCE
                 // half step 1: K step 0, channel tiles 2, 3 -- a pixel fragment is dead after its six MFMAs: K step 1's takes its registers
-                WT_LOAD_W(0, buf, 1, 0)
+                WT_LOAD_W(0, bw, 1, 0)
                 WT_FENCE
                 WT_MFMA6(1, 1, 0, z) WT_FENCE WT_LOAD_X(0, ap, 1) WT_FENCE
                 WT_MFMA6(1, 1, 1, z) WT_FENCE WT_LOAD_X(1, ap, 1) WT_FENCE
                 WT_MFMA6(1, 1, 2, z) WT_FENCE WT_LOAD_X(2, ap, 1) WT_FENCE
                 WT_MFMA6(1, 1, 3, z) WT_FENCE WT_LOAD_X(3, ap, 1) WT_FENCE
                 // half step 2: K step 1, channel tiles 0, 1
-                WT_LOAD_W(1, buf, 1, 1)
+                WT_LOAD_W(1, bw, 1, 1)
                 WT_FENCE
                 WT_MFMA6(0, 0, 0, false) WT_MFMA6(0, 0, 1, false) WT_MFMA6(0, 0, 2, false) WT_MFMA6(0, 0, 3, false)
                 WT_FENCE
@@ -356,7 +395,7 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
                 if (tap + 1 < 9) {
                     const int ky1 = (tap + 1) / 3, kx1 = tap + 1 - 3 * ky1;
                     const char* const ap1 = a0 + (ky1 * WT_HX + kx1) * WT_PSB;
-                    WT_LOAD_W(0, (tap + 1) % 3, 0, 0)
+                    WT_LOAD_W(0, bw1, 0, 0)
                     WT_FENCE
                     WT_MFMA6(1, 1, 0, false) WT_FENCE WT_LOAD_X(0, ap1, 0) WT_FENCE
                     WT_MFMA6(1, 1, 1, false) WT_FENCE WT_LOAD_X(1, ap1, 0) WT_FENCE
@@ -371,8 +410,10 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
 #undef WT_LOAD_W
 #undef WT_MFMA6
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WT_STAMP(2)
             __builtin_amdgcn_s_barrier();                            // E: this wave's reads of the input tile are back
             asm volatile("" ::: "memory");
+            WT_STAMP(4)                                                  // 4: waiting at E
             (void)cc;
         };
         chunk(0, std::true_type{});
@@ -381,16 +422,26 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
 
         // ---- epilogue, straight from the accumulators (wepilogue above), one instance per combination of formats ----
         switch ((a.skip ? 1 : 0) | ((a.fmt & CV_FMT_SKIP) ? 2 : 0) | ((a.fmt & CV_FMT_Y) ? 4 : 0)) {
-            case 0: wepilogue<false, false, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;
-            case 1: wepilogue<true, false, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;
-            case 3: wepilogue<true, true, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;
-            case 4: case 6: wepilogue<false, false, true>(a, q, mainv, corrv, wv, lane, pix, cb); break;
-            case 5: wepilogue<true, false, true>(a, q, mainv, corrv, wv, lane, pix, cb); break;
-            case 7: wepilogue<true, true, true>(a, q, mainv, corrv, wv, lane, pix, cb); break;
-            default: wepilogue<false, false, false>(a, q, mainv, corrv, wv, lane, pix, cb); break;      // (2: a skip format without a skip tensor)
+            case 0: wepilogue<false, false, false>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;
+            case 1: wepilogue<true, false, false>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;
+            case 3: wepilogue<true, true, false>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;
+            case 4: case 6: wepilogue<false, false, true>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;
+            case 5: wepilogue<true, false, true>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;
+            case 7: wepilogue<true, true, true>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;
+            default: wepilogue<false, false, false>(a, q, mainv, corrv, wv, lane, pix, cb, lbias); break;      // (2: a skip format without a skip tensor)
         }
+        WT_STAMP(5)                                                      // 5: the epilogue (issue side: the stores drain behind it)
     }
+#ifdef H3W_PROF
+    if (tid == 0 && blockIdx.x < 1024) for (int k = 0; k < 8; ++k) g_h3wprof[blockIdx.x * 8 + k] = psum[k];
+#endif
 }
+
+#ifdef H3W_PROF
+extern "C" int pnp_conv_h3w_prof_read(unsigned* out /* [1024][8] */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h3wprof), sizeof(unsigned) * 1024 * 8);
+}
+#endif
 
 hipError_t launch_conv3x3_f16x3_wide(hipStream_t s, const float* x, const float* w, const float* bias, const float* skip, float* y,
                                      int n, int C, int H, int W, int relu, int fmt) {

@@ -90,7 +90,7 @@ def store_hazards(body, window=2):
     return bad
 
 
-def dma_order_violations(body, group=4, ahead=0, labels=None):
+def dma_order_violations(body, group=4, ahead=0, labels=None, primed=0):
     """LDS-DMA ordering of the f16x3 convolution kernels (kernels_conv_f16x3.hip / kernels_conv_f16x3_wide.hip): a tap's weights
     are written into LDS by `buffer_load_dwordx4 ... lds` (D below) and published to the other waves by `s_waitcnt vmcnt(n)` + `s_barrier`,
     where n counts the operations issued BEHIND the DMAs that may stay in flight.  That count is right only while every D of a group
@@ -98,14 +98,15 @@ def dma_order_violations(body, group=4, ahead=0, labels=None):
     The walk keeps the operations that may still be in flight (a wait truncates the list to its youngest n); at a barrier the groups
     whose D are all retired count as PUBLISHED.  `ahead` = how many groups may be in flight across a barrier: 0 for the narrow kernel
     (double-buffered: a tap's group lands before the next barrier), 1 for the wide one (triple-buffered: the group requested in tap T is
-    waited for at the end of tap T + 1).  Reported: (a) group g issued while fewer than g - ahead groups are published -- a buffer would
+    waited for at the end of tap T + 1).  `primed`: groups more than `ahead` that a prologue may request in front of the first barrier
+    (it drains them all before it arrives there; the wide kernel fills three of its four buffers this way).  Reported: (a) group g issued while fewer than g - ahead groups are published -- a buffer would
     be overwritten, or read, with its DMA unfinished; (b) a kernel that ends (s_endpgm) with a D possibly in flight.  A plain access that
     slips between or in front of a group's DMAs with a counted wait behind it leaves a D among the youngest n: that group stays
     unpublished and (a) fires.  `labels` ({label: index into body}, kernels_of): every BACKWARD branch is followed again (ahead + 1 more times) -- the loop
     body is walked with the state the pass before left, so the hand-over from a loop's last group to its first is checked
     too (round 5's walk was linear and never saw a back edge)."""
     bad = []
-    st = {'inflight': [], 'run': 0, 'published': 0}
+    st = {'inflight': [], 'run': 0, 'published': primed}
 
     def step(idx, ins):
         if ins.startswith(('buffer_load', 'buffer_store', 'global_load', 'global_store', 'flat_load', 'flat_store', 'buffer_atomic', 'global_atomic',
@@ -147,8 +148,11 @@ def scan_text(text):
         n += sum(1 for ins in k['body'] if re.match(r'buffer_store_dwordx[34]', ins))
         bad += [(name, a, b) for a, b in store_hazards(k['body'])]
         if '_h3' in name and any(ins.startswith('buffer_load') and ins.rstrip().endswith(' lds') for ins in k['body']):
-            ahead = 1 if '_h3w' in name else 0                   # the wide kernel's weight stream runs one tap further ahead (three buffers)
-            bad += [(name, 'LDS-DMA order: ' + why, ins) for _, why, ins in dma_order_violations(k['body'], ahead=ahead, labels=k['labels'])]
+            # the wide kernel: four buffers, the group requested in tap T is waited for at the end of tap T + 1 (one group in flight across a
+            # barrier); its prologue requests three taps back to back and drains them
+            wide = '_h3w' in name
+            bad += [(name, 'LDS-DMA order: ' + why, ins)
+                    for _, why, ins in dma_order_violations(k['body'], ahead=1 if wide else 0, primed=1 if wide else 0, labels=k['labels'])]
     return bad, n
 
 

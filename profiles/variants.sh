@@ -23,10 +23,10 @@ case "$1" in
 build)
   F=$2; NAME=$3; FLAGS=$4
   make -C $C -j4 > /dev/null
-  { [ "$F" = kernels_conv_f16x3.hip ] || [ "$F" = kernels_pix2x2_f16x3.hip ]; } && FLAGS="$FLAGS -fno-slp-vectorize"     # the Makefile's per-file flag
+  { [ "$F" = kernels_conv_f16x3.hip ] || [ "$F" = kernels_conv_f16x3_wide.hip ] || [ "$F" = kernels_pix2x2_f16x3.hip ]; } && FLAGS="$FLAGS -fno-slp-vectorize"     # the Makefile's per-file flag
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off $FLAGS -c $C/$F -o $V/${NAME}_${F%.hip}.o
   OBJS=""
-  for o in api kernels_generic kernels_fused256 kernels_fused512 kernels_slice256 kernels_conv kernels_conv_f16x3 kernels_pix2x2_f16x3; do
+  for o in api kernels_generic kernels_fused256 kernels_fused512 kernels_slice256 kernels_conv kernels_conv_f16x3 kernels_conv_f16x3_wide kernels_pix2x2_f16x3; do
     if [ "$o.hip" = "$F" ]; then OBJS="$OBJS $V/${NAME}_$o.o"; else OBJS="$OBJS $C/$o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib_$NAME.so $OBJS -ldl
@@ -35,7 +35,7 @@ build)
 knobs)
   mkdir -p $V/knobs
   OBJS=""
-  for o in api kernels_generic kernels_fused256 kernels_fused512 kernels_slice256 kernels_conv kernels_conv_f16x3 kernels_pix2x2_f16x3; do
+  for o in api kernels_generic kernels_fused256 kernels_fused512 kernels_slice256 kernels_conv kernels_conv_f16x3 kernels_conv_f16x3_wide kernels_pix2x2_f16x3; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off -DPNP_EXPERIMENT_KNOBS $2 -c $C/$o.hip -o $V/knobs/$o.o &
     OBJS="$OBJS $V/knobs/$o.o"
   done

@@ -394,12 +394,14 @@ def test_split_chain_float_engine_vs_oracle(env, golden_inputs, solver, monkeypa
         assert rel_l2(x[b], ref) <= 2e-6, (b, rel_l2(x[b], ref))
 
 
-@pytest.mark.skipif(os.environ.get('PNP_SKIP_SLOW') == '1',
-                    reason='about 2 minutes on a fresh box (MIOpen searches DRUNet\'s batch-64 convolutions once); PNP_SKIP_SLOW=1 skips it')
 def test_config4_shard_full_batch_drunet(env, monkeypatch):
     """Config 4's per-GPU shard at full size: PNP_ADMM_CNC_D with DRUNet on 512 slices of 256x256, Q_Cartesian30,
-    S6:577 preset, ONE iteration (two DRUNet forwards over the whole shard).  (a) the 64 slices of one CNN batch
-    run alone are bit-equal to the same slices inside the shard; (b) oracle-loop spot check on the last slice."""
+    S6:577 preset, ONE iteration (two DRUNet forwards over the whole shard) on the split-half f16 backend -- every convolution of the
+    U-Net on libpnpmri.so.  (a) the 64 slices of one CNN batch run alone are bit-equal to the same slices inside the shard; (b) the
+    oracle loop driven by the same denoiser on the last slice <= 1e-5; (c) the PyTorch / MIOpen backend on the shard's last 128 slices
+    (two CNN batches: MIOpen compiles and searches every new convolution shape on a fresh box -- round 5 ran it on all 512, 105 s of the
+    suite; the per-slice comparison does not get stronger with more slices of the same shape): every slice within 2e-5 of the f16x3 run,
+    its second batch alone bit-equal to itself inside the call, its last slice <= 1e-5 from the oracle loop driven by the MIOpen denoiser."""
     torch, D, S = env['torch'], env['D'], env['S']
     from pnp_admm_cnc_mri_amd import synthetic as SY, utils_pnp
     monkeypatch.setattr(torch.backends.cudnn, 'deterministic', False)           # as in test_config3_full_batch_properties
@@ -413,28 +415,29 @@ def test_config4_shard_full_batch_drunet(env, monkeypatch):
     net, nlm, _ = D.build(name)
     sd = D.seeded_state_dict(net, 1003)
     opts = dict(alpha=1, iter_num=1, lambda1=0.8, reo=0.8, b=0.45)               # S6:577, 1 iteration
-    full, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys, model=sd, **opts)
-    full = np.stack(full[:B])
-    assert np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
-    sub, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[448:512], model=sd, **opts)
-    assert np.array_equal(np.stack(sub[:64]), full[448:512])
-    net.load_state_dict(sd)
-    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), 1, 49, nlm * 255., 1.0)[1])
-    den = D.Denoiser(name, net.eval(), nlm, sigmas=sig).to(torch.device('cuda'))
-
-    def denoise(a, i):
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
-        return den(t, i)[0, 0].cpu().numpy()
-    ref = O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), mask, denoise, 1, 1, 0.8, 0.8, 0.45)
-    assert rel_l2(full[B - 1], ref) <= 1e-5, rel_l2(full[B - 1], ref)
-    # (c) the split-half f16 backend on the same shard (every convolution of the U-Net on libpnpmri.so): all 512 slices within 2e-5
-    # of the PyTorch / MIOpen run, the last CNN batch alone bit-equal to itself inside the shard
     fh, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys, model=sd, cnn_backend='hip_f16x3', **opts)
     fh = np.stack(fh[:B])
-    per_slice = np.linalg.norm((fh - full).reshape(B, -1), axis=1) / np.linalg.norm(full.reshape(B, -1), axis=1)
-    assert np.isfinite(fh).all() and fh.min() >= 0 and fh.max() <= 1 and per_slice.max() <= 2e-5, per_slice.max()
+    assert np.isfinite(fh).all() and fh.min() >= 0 and fh.max() <= 1
     subh, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[448:512], model=sd, cnn_backend='hip_f16x3', **opts)
     assert np.array_equal(np.stack(subh[:64]), fh[448:512])
+    net.load_state_dict(sd)
+    sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), 1, 49, nlm * 255., 1.0)[1])
+
+    def oracle_last(backend):
+        den = D.Denoiser(name, net.eval(), nlm, sigmas=sig, backend=backend).to(torch.device('cuda'))
+
+        def denoise(a, i):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None].cuda()
+            return den(t, i)[0, 0].cpu().numpy()
+        return O.pnp_admm_cnc(ys[B - 1].astype(np.complex128), mask, denoise, 1, 1, 0.8, 0.8, 0.45)
+    assert rel_l2(fh[B - 1], oracle_last('hip_f16x3')) <= 1e-5
+    full, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[384:512], model=sd, cnn_backend='torch', **opts)
+    full = np.stack(full[:128])
+    per_slice = np.linalg.norm((fh[384:512] - full).reshape(128, -1), axis=1) / np.linalg.norm(full.reshape(128, -1), axis=1)
+    assert np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1 and per_slice.max() <= 2e-5, per_slice.max()
+    sub, _ = S.PNP_ADMM_CNC_D(name, mask, None, y=ys[448:512], model=sd, cnn_backend='torch', **opts)
+    assert np.array_equal(np.stack(sub[:64]), full[64:128])
+    assert rel_l2(full[127], oracle_last('torch')) <= 1e-5
 
 
 # ----------------------------------------------------------------------------------------------
