@@ -99,8 +99,16 @@ __device__ __forceinline__ void wput_input(float* xin, int h, const f32x4 (&v)[W
         }
 }
 
+// Which output channel a row of the transposed product is.  The compute waves read their weight fragments PERMUTED: row m of channel tile
+// ct = 2 g + e is output channel 32 g + 8 (m >> 2) + 4 e + (m & 3) of the block (wt_wrow_offset: where lane i = m finds it among the packed
+// fragments -- a per-lane base address and immediate offsets, nothing at run time).  An accumulator quad of lane (i, kb) in tile (ct, pt) is then
+// channels 32 g + 8 kb + 4 e .. + 3 of pixel (tile row 4 w + pt, column h3_row_pixel(i)): the two tiles of a pair give a lane EIGHT consecutive
+// channels -- 32 bytes of a float32 pixel, or 16 bytes of hi halves + 16 bytes of lo halves of a split one -- and every store is 16 bytes
+// straight from the registers with no exchange between lanes.  (Price: the sixteen rows a 16-lane group of a weight read touches cover only
+// eight 16-byte bank slots -- those reads take 8 LDS cycles instead of 4; the LDS is a third busy in this kernel.)
+__device__ __forceinline__ int wt_wrow_offset(int i, int kb) { return (i >> 3) * 2048 + (8 * ((i >> 2) & 1) + (i & 3)) * 16 + kb * 256; }
+
 // The epilogue of an item, straight from the accumulators: y = relu?(acc + bias + skip), ONE 16-byte store per lane and (ct, pt).
-// Accumulator reg r of lane (i, kb), tile (ct, pt) = channel 16 ct + 4 kb + r of pixel (tile row 4 w + pt, column h3_row_pixel(i)).
 // SKIP / KSPLIT / YSPLIT: a skip tensor is added / it is in the split activation format / y is written in it (f16x3_common.h) -- compile-time,
 // one instance each: sixteen stores behind uniform branches would put a dozen branches per store on the wave's critical path.
 // The two orders of the sum are the narrow kernel's (store_rows32 / store_rows32_fmt): all-float32 tensors acc + (skip + bias), any split
@@ -108,7 +116,6 @@ __device__ __forceinline__ void wput_input(float* xin, int h, const f32x4 (&v)[W
 template <bool SKIP, bool KSPLIT, bool YSPLIT>
 __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, const f32x4 (&mainv)[4][4], const f32x4 (&corrv)[4][4],
                                           int wv, int lane, const int pix, const int cb, const float* lbias) {
-    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, 64 * cb);
     const __amdgpu_buffer_rsrc_t rk = image_rsrc((SKIP ? a.skip : a.y) + (size_t)q.img * a.H * a.W * (pix >> 2), a.H, a.W, pix, 64 * cb);
     // (opaque copy of the lane number: what is derived from it -- and the biases -- is computed HERE, per item; hoisted out of the item loop as
@@ -118,71 +125,93 @@ __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, 
     const int i = ln & 15, kb = ln >> 4;
     constexpr bool FMT = KSPLIT || YSPLIT;
     const int gx = q.x0 + h3_row_pixel(i);
-    // byte offsets inside the pixel's block of 64 channels: float32 -- this lane's four channels 16 ct + 4 kb ..; split -- after the
-    // lane-row exchange even rows hold the eight hi halves of channels 16 ct + 8 (kb >> 1) .., odd rows the eight lo halves (+ 128)
-    const int of32 = 16 * kb, osp = 16 * (kb >> 1) + 128 * (kb & 1);
+    // byte offsets of this lane's eight channels 32 g + 8 kb .. inside the pixel's block of 64: float32 -- 128 g + 32 kb (+ 16: the second four);
+    // split -- hi halves at 64 g + 16 kb, lo halves 128 bytes behind them
+    const int of32 = 32 * kb, osp = 16 * kb;
     // ReLU without a branch: v < thr ? 0 : v with thr = 0, or -inf (never true; NaN stays NaN either way: torch.nn.ReLU)
     const float thr = a.relu ? 0.f : -__builtin_inff();
     // byte offset of this lane's pixel in tile row pt; rows below the image: beyond the buffer's range by themselves; columns right of
     // it: such an offset
+#ifdef WT_ABL_OOB                                                 // timing-only ablation (results wrong by design): every store out of range, dropped by the address unit
+    const int pb0 = -256, pbs = 0;
+#else
     const int pb0 = gx < a.W ? ((q.y0 + 4 * wv) * a.W + gx) * pix : -256, pbs = gx < a.W ? a.W * pix : 0;
+#endif
 #define WT_PB(pt_) (pb0 + (pt_) * pbs)
-    f32x4 bs[4];                                                 // this lane's four channels per channel tile: from LDS (the helpers put them there)
+#ifdef WT_ABL_NOST                                                // timing-only ablation: the values are computed, no store is issued
+#define WT_STORE(o_, off_) asm volatile("" :: "v"(o_))
+#else
+#define WT_STORE(o_, off_) __builtin_amdgcn_raw_buffer_store_b128(o_, ry, off_, 0, 0)
+#endif
+    f32x4 bs[2][2];                                              // [g][e]: this lane's biases, from LDS (the helpers put them there)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bs[ct] = *reinterpret_cast<const f32x4*>(lbias + 16 * ct + 4 * kb);
-    u32x4v kq[SKIP ? 4 : 1][4];
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) bs[g][e] = *reinterpret_cast<const f32x4*>(lbias + 32 * g + 8 * kb + 4 * e);
+    u32x4v kq[SKIP ? 4 : 1][2][2];                               // [pt][g][float32: e / split: hi, lo]
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
         if (SKIP && !(pt & 1)) {                                 // the eight requests of two tile rows at once: two memory round trips per item
 #pragma unroll                                                   // (all sixteen at once: 64 registers more than the accumulators leave)
             for (int p2 = pt; p2 < pt + 2; ++p2)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    kq[p2][ct] = __builtin_amdgcn_raw_buffer_load_b128(rk, WT_PB(p2) + (KSPLIT ? 32 * ct + osp : 64 * ct + of32), 0, 0);
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        kq[p2][g][e] = __builtin_amdgcn_raw_buffer_load_b128(rk, WT_PB(p2) + (KSPLIT ? 64 * g + osp + 128 * e : 128 * g + of32 + 16 * e), 0, 0);
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            f32x4 v;
+        for (int g = 0; g < 2; ++g) {
+            f32x4 v[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(corrv[ct][pt][r], H3_RSCALE, mainv[ct][pt][r]);
-            if (FMT) {
-                v += bs[ct];
-                if (SKIP) {
-                    if (KSPLIT) {
-                        // undo the producer's lane-row exchange: afterwards hq = this lane's four hi halves, lq its four lo halves
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(kq[SKIP ? pt : 0][ct].x, kq[SKIP ? pt : 0][ct].z, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(kq[SKIP ? pt : 0][ct].y, kq[SKIP ? pt : 0][ct].w, false, false);
-                        const h4 hq = __builtin_bit_cast(h4, u32x2v{s0[0], s1[0]}), lq = __builtin_bit_cast(h4, u32x2v{s0[1], s1[1]});
+            for (int e = 0; e < 2; ++e) {
+                const int ct = 2 * g + e;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += unsplit(hq[r], lq[r]);
-                    } else {
-                        { const u32x4v k_ = kq[SKIP ? pt : 0][ct]; v += f32x4{__uint_as_float(k_.x), __uint_as_float(k_.y), __uint_as_float(k_.z), __uint_as_float(k_.w)}; }
+                for (int r = 0; r < 4; ++r) v[e][r] = fmaf(corrv[ct][pt][r], H3_RSCALE, mainv[ct][pt][r]);
+            }
+            if (SKIP) {
+                f32x4 k[2];
+                if (KSPLIT) {
+                    const h8 kh = __builtin_bit_cast(h8, kq[pt][g][0]), kl = __builtin_bit_cast(h8, kq[pt][g][1]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) k[e][r] = unsplit(kh[4 * e + r], kl[4 * e + r]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const u32x4v k_ = kq[pt][g][e];
+                        k[e] = f32x4{__uint_as_float(k_.x), __uint_as_float(k_.y), __uint_as_float(k_.z), __uint_as_float(k_.w)};
                     }
                 }
-            } else if (SKIP) {
-                { const u32x4v k_ = kq[SKIP ? pt : 0][ct]; v += f32x4{__uint_as_float(k_.x), __uint_as_float(k_.y), __uint_as_float(k_.z), __uint_as_float(k_.w)} + bs[ct]; }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) v[e] = FMT ? (v[e] + bs[g][e]) + k[e] : v[e] + (k[e] + bs[g][e]);
             } else {
-                v += bs[ct];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) v[e] += bs[g][e];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] < thr ? 0.f : v[r];
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[e][r] = v[e][r] < thr ? 0.f : v[e][r];
             if (YSPLIT) {
-                h4 hi, lo;
-                split4(v, hi, lo);
-                const u32x2v hu = __builtin_bit_cast(u32x2v, hi), lu = __builtin_bit_cast(u32x2v, lo);
-                // odd lane rows of the hi dwords <-> even lane rows of the lo dwords (cdna_hip_programming.md T21, for rows of 16 lanes):
-                // even rows then hold [own hi | partner's hi], odd rows [partner's lo | own lo] -- eight consecutive channels each
-                const auto s0 = __builtin_amdgcn_permlane16_swap(hu.x, lu.x, false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(hu.y, lu.y, false, false);
-                const u32x4v o = {s0[0], s1[0], s0[1], s1[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ry, WT_PB(pt) + 32 * ct + osp, 0, 0);
+                h4 h0, l0, h1, l1;
+                split4(v[0], h0, l0);
+                split4(v[1], h1, l1);
+                const h8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}, lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                WT_STORE(__builtin_bit_cast(u32x4v, hi), WT_PB(pt) + 64 * g + osp);
+                WT_STORE(__builtin_bit_cast(u32x4v, lo), WT_PB(pt) + 64 * g + osp + 128);
             } else {
-                const u32x4v o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ry, WT_PB(pt) + 64 * ct + of32, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const u32x4v o = {__float_as_uint(v[e][0]), __float_as_uint(v[e][1]), __float_as_uint(v[e][2]), __float_as_uint(v[e][3])};
+                    WT_STORE(o, WT_PB(pt) + 128 * g + of32 + 16 * e);
+                }
             }
         }
     }
 #undef WT_PB
+#undef WT_STORE
 }
 
 #define WT_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory")
@@ -310,7 +339,7 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
     // channel 16 ct + 4 kb + r of pixel (tile row 4 w + pt, column h3_row_pixel(i)).
     const int i = lane & 15, kb = lane >> 4;
     const char* const a0 = reinterpret_cast<const char*>(xin) + (4 * wv * WT_HX + h3_row_pixel(i)) * WT_PSB + h3_chunk_pos(kb, 0, 0);
-    const char* const b0 = reinterpret_cast<const char*>(&wbuf[0][0]) + lane * 16;
+    const char* const b0 = reinterpret_cast<const char*>(&wbuf[0][0]) + wt_wrow_offset(i, kb);      // (permuted rows: wepilogue's note)
     int rot = 0;                                                 // buffer of the current tap = global tap % 4 (uniform)
 #ifdef H3W_PROF
     unsigned psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -329,11 +358,12 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
 #define WT_LOAD_X(pt_, ap_, s2_)                                                                         \
             xh[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_));       \
             xl[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_) + 16);
-            // weight fragments of (buffer, K step s2, channel-tile pair cp): fragment f = (s2 * 4 + ct) * 2 + part, 1 KiB each
+            // weight fragments of (buffer, K step s2, channel-tile pair cp = g): packed fragment f = (s2 * 4 + nt) * 2 + part, 1 KiB each; the rows of
+            // tile 2 g + e sit in fragments nt = 2 g and 2 g + 1 (the lane's base, wt_wrow_offset), 64 e bytes apart
 #define WT_LOAD_W(slot_, bw_, s2_, cp_)                                                                  \
             _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                           \
-                wh[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2)));      \
-                wl[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2) + 1));  \
+                wh[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_)) * 2)) + 64 * c_);      \
+                wl[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_)) * 2) + 1) + 64 * c_);  \
             }
             // the six MFMAs of (pixel tile pt) x (channel-tile pair cp): main += w_hi x_hi; corr += w_lo x_hi; corr += w_hi x_lo -- the order
             // of the narrow kernel (x_hi w_hi; x_hi w_lo; x_lo w_hi), the two dependent corr updates two instructions apart
