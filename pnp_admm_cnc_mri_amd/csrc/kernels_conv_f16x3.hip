@@ -586,7 +586,7 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, c
         // items of its own -- below that the 8 x 16 tiles on two workgroups per unit spread a small layer better
         const long long items16 = (long long)n * ((W + 15) / 16) * ((H + 15) / 16) * (C >> 6);
         const int mode = conv_wide_mode();
-        if (mode == 1 || (mode < 0 && items16 >= 2LL * cus)) return launch_conv3x3_f16x3_wide(s, x, w, bias, skip, y, n, C, H, W, relu, fmt);
+        if (mode >= 1 || (mode < 0 && items16 >= 2LL * cus)) return launch_conv3x3_f16x3_wide(s, x, w, bias, skip, y, n, C, H, W, relu, fmt);
     }
     switch (dilation) {
         case 1: return launch_h3_dil<1>(s, a, items, cus);

@@ -150,9 +150,11 @@ def scan_text(text):
         if '_h3' in name and any(ins.startswith('buffer_load') and ins.rstrip().endswith(' lds') for ins in k['body']):
             # the wide kernel: four buffers, the group requested in tap T is waited for at the end of tap T + 1 (one group in flight across a
             # barrier); its prologue requests three taps back to back and drains them
-            wide = '_h3w' in name
+            # (the pipe kernel, kernels_conv_f16x3_pipe.hip: the same protocol with 8 KiB blocks -- two DMAs per helper wave and pass-tap)
+            wide, pipe = '_h3w' in name, '_h3p' in name
             bad += [(name, 'LDS-DMA order: ' + why, ins)
-                    for _, why, ins in dma_order_violations(k['body'], ahead=1 if wide else 0, primed=1 if wide else 0, labels=k['labels'])]
+                    for _, why, ins in dma_order_violations(k['body'], group=2 if pipe else 4, ahead=1 if wide or pipe else 0,
+                                                            primed=1 if wide or pipe else 0, labels=k['labels'])]
     return bad, n
 
 

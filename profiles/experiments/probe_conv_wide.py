@@ -89,10 +89,10 @@ if __name__ == '__main__':
         res.setdefault(mode, []).append(json.loads(line[0][7:]))
     a, b = res['0'][0]['check'], res['1'][0]['check']
     bad = [k for k in a if a[k] != b.get(k)]
-    print('check: %d cases, %d differ between narrow and wide' % (len(a), len(bad)))
+    print('check: %d cases, %d differ between narrow (PNP_CONV_WIDE=0) and wide (1)' % (len(a), len(bad)))
     for k in bad[:40]:
         print('   DIFF', k)
     for k in res['0'][0]['time']:
-        print('%-38s narrow %s   wide %s   (ms, fraction of the 2.5 PFLOP/s f16 peak; two runs each)' % (
-            k, ' / '.join('%.4f %.3f' % tuple(r['time'][k]) for r in res['0']), ' / '.join('%.4f %.3f' % tuple(r['time'][k]) for r in res['1'])))
+        print('%-38s narrow %s   wide %s   (ms; two runs each)' % (
+            k, ' / '.join('%.4f' % r['time'][k][0] for r in res['0']), ' / '.join('%.4f' % r['time'][k][0] for r in res['1'])))
     sys.exit(1 if bad else 0)
