@@ -39,7 +39,7 @@ extern "C" {
 #define PNP_E_STATE      -3   /* call order (e.g. run before upload)        */
 #define PNP_E_NOMEM      -4
 
-#define PNP_ABI_VERSION   10
+#define PNP_ABI_VERSION   11
 
 typedef struct pnp_ctx pnp_ctx;
 
@@ -239,6 +239,11 @@ int pnp_conv3x3_pack_f16x3(void* hip_stream, const float* w_oihw_dev, float* w_p
 #define PNP_FMT_Y_SPLIT    4
 int pnp_conv3x3_nhwc_f16x3_fmt(void* hip_stream, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
                                const float* skip_dev, float* y_dev, int n, int C, int H, int W, int relu, int dilation, int fmt);
+/* Which kernel the three f16x3 conv3x3 entry points above launch at dilation 1 (the results are bit-equal; tests and A/B measurements pin
+ * one): -1 = by size (default: the WIDE kernel -- 16 x 16 pixel tiles, 64 x 64 wave tiles, compute + helper waves, kernels_conv_f16x3_wide.hip --
+ * once every compute unit has two items of its own, the narrow one -- 8 x 16 tiles, two workgroups per unit -- below that), 0 = narrow always,
+ * 1 = wide always.  Process-wide; returns the previous setting.  The environment variable PNP_CONV_WIDE sets the initial value.  New in ABI 11. */
+int pnp_conv3x3_f16x3_set_variant(int variant);
 /* pnp_conv3x3_tail_nchw (below) in the f16x3 arithmetic: x [n][H][W][64] (NHWC), w a torch Conv2d(64, cout, 3) weight (split inside the
  * kernel), 1 <= cout <= 4 -> y [n][cout][H][W] (NCHW), + bias.  On the vector units this layer costs as much as a 64 -> 64 layer of the
  * f16x3 kernel; as a 16-column matrix product it is bound by reading its input.  Same operand range as above.  New in ABI 9. */

@@ -68,6 +68,7 @@ SIGNATURES = {
     'pnp_conv3x3_c64_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_c64_pack_f16x3': (C.c_int, [_vp, _vp, _vp]),
     'pnp_conv3x3_nhwc_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'pnp_conv3x3_f16x3_set_variant': (C.c_int, [C.c_int]),
     'pnp_conv3x3_nhwc_f16x3_fmt': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'pnp_conv3x3_pack_f16x3': (C.c_int, [_vp, _vp, _vp, C.c_int]),
     'pnp_conv3x3_tail_nchw_f16x3': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -87,7 +88,7 @@ SIGNATURES = {
     'pnp_path_name': (C.c_char_p, [ctx_p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

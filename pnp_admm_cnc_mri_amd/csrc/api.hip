@@ -946,6 +946,7 @@ int pnp_conv3x3_nhwc_f16x3_fmt(void* stream, const float* x, const float* w, con
     HIPCHK(launch_conv3x3_f16x3((hipStream_t)stream, x, w, bias, skip, y, n, C, H, W, relu, dilation, fmt));
     return PNP_OK;
 }
+int pnp_conv3x3_f16x3_set_variant(int variant) { return conv_set_wide_mode(variant); }
 int pnp_conv3x3_pack_f16x3(void* stream, const float* w_oihw, float* w_packed, int C) {
     if (!w_oihw || !w_packed || w_oihw == w_packed) return fail(PNP_E_ARG, "pnp_conv3x3_pack_f16x3: null or aliased pointers");
     if (C < 64 || C > 1024 || C % 64) return fail(PNP_E_ARG, "pnp_conv3x3_pack_f16x3: C must be a multiple of 64 in 64..1024 (got %d)", C);

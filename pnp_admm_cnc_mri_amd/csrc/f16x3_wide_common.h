@@ -78,13 +78,13 @@ __device__ __forceinline__ void wput_input(float* xin, int h, const f32x4 (&v)[W
         }
 }
 
-// Which output channel a row of the transposed product is.  The compute waves read their weight fragments PERMUTED: row m of channel tile
-// ct = 2 g + e is output channel 32 g + 8 (m >> 2) + 4 e + (m & 3) of the block (wt_wrow_offset: where lane i = m finds it among the packed
-// fragments -- a per-lane base address and immediate offsets, nothing at run time).  An accumulator quad of lane (i, kb) in tile (ct, pt) is then
-// channels 32 g + 8 kb + 4 e .. + 3 of pixel (tile row 4 w + pt, column h3_row_pixel(i)): the two tiles of a pair give a lane EIGHT consecutive
-// channels -- 32 bytes of a float32 pixel, or 16 bytes of hi halves + 16 bytes of lo halves of a split one -- and every store is 16 bytes
-// straight from the registers with no exchange between lanes.  (Price: the sixteen rows a 16-lane group of a weight read touches cover only
-// eight 16-byte bank slots -- those reads take 8 LDS cycles instead of 4; the LDS is a third busy in this kernel.)
+// Which output channel a row of the transposed product is.  The weight fragments reach the compute waves PERMUTED: row m of channel tile
+// ct = 2 g + e is output channel 32 g + 8 (m >> 2) + 4 e + (m & 3) of the block.  wt_wrow_offset: where, among the packed fragments of a tap,
+// lane (i = m, kb) finds it (relative to fragment nt = 2 g, + 64 e) -- the helper waves' LDS-DMA uses it as its per-lane global address, so the
+// permutation costs nothing and the LDS image is read at lane * 16.  An accumulator quad of lane (i, kb) in tile (ct, pt) is then channels
+// 32 g + 8 kb + 4 e .. + 3 of pixel (tile row 4 w + pt, column h3_row_pixel(i)): the two tiles of a pair give a lane EIGHT consecutive channels
+// -- 32 bytes of a float32 pixel, or 16 bytes of hi halves + 16 bytes of lo halves of a split one -- and every store is 16 bytes straight from
+// the registers with no exchange between lanes.
 __device__ __forceinline__ int wt_wrow_offset(int i, int kb) { return (i >> 3) * 2048 + (8 * ((i >> 2) & 1) + (i & 3)) * 16 + kb * 256; }
 
 #define WT_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory")

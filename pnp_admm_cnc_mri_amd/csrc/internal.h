@@ -86,7 +86,8 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* wfra
 // weights, bit-equal results; launch_conv3x3_f16x3 dispatches to it (conv_wide_mode below) -- callers never name it
 hipError_t launch_conv3x3_f16x3_wide(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,
                                      float* y, int n, int C, int H, int W, int relu, int fmt);
-int conv_wide_mode();            // developer knob PNP_CONV_WIDE, read once: unset / -1 = by size, 0 = never, 1 = always (dilation 1)
+int conv_wide_mode();            // -1 = by size, 0 = never, 1 = always (dilation 1); initial value: PNP_CONV_WIDE; pnp_conv3x3_f16x3_set_variant
+int conv_set_wide_mode(int m);   // returns the previous setting
 hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const float* x2_nhwc /* null or added to x */, const float* w_oihw,
                                      const float* bias, float* y_nchw, int n, int cout, int H, int W,
                                      int shuffle_h = 0, int shuffle_w = 0 /* FFDNet: cout = 4 written as one pixel-shuffled [shuffle_h][shuffle_w] channel */);

@@ -597,10 +597,12 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, c
     }
 }
 
-int conv_wide_mode() {
-    static const int mode = [] { const char* e = getenv("PNP_CONV_WIDE"); return e ? atoi(e) : -1; }();
+static int& wide_mode_ref() {
+    static int mode = [] { const char* e = getenv("PNP_CONV_WIDE"); return e ? atoi(e) : -1; }();
     return mode;
 }
+int conv_wide_mode() { return wide_mode_ref(); }
+int conv_set_wide_mode(int m) { int& r = wide_mode_ref(); const int old = r; r = m < 0 ? -1 : m > 0 ? 1 : 0; return old; }
 
 hipError_t launch_conv_pack_w_f16x3(hipStream_t s, const float* w_oihw, float* wfrag, int C) {
     if (C < 64 || C > 1024 || (C & 63)) return hipErrorInvalidValue;

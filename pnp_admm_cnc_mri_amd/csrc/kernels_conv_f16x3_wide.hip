@@ -182,13 +182,23 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
         // T + 2 are in place: the compute waves may read tap T + 2's first fragments before B_(T+2).  (Three buffers with the wait one group
         // later -- this kernel's first version -- let that read race the DMA; three buffers with the wait in the requesting tap put a DMA's
         // latency on the barrier: profiles/conv_f16x3_wide_r06.txt.)
+        // The DMA also PERMUTES the rows (f16x3_wide_common.h): LDS unit u = (s2 * 4 + ct) * 2 + part is lane (i, kb)'s fragment of channel tile
+        // ct = 2 g + e, whose row i is output channel 32 g + 8 (i >> 2) + 4 e + (i & 3) -- fetched from packed fragment nt = 2 g + (i >> 3) by the
+        // per-lane GLOBAL address (wt_wrow_offset) -- so the compute waves read at lane * 16 with no bank conflict and still hold eight
+        // consecutive channels per tile pair.  Helper wave w copies units w + 4 j; their positions in the packed tap go in the SCALAR offset.
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 9 * a.C * a.C * 4, 0x00020000);
-        const int wvoff = h * 16, wbase = cb * period * (H3_TAP16 * 16);
+        const int wvoff = wt_wrow_offset(lane & 15, lane >> 4), wbase = cb * period * (H3_TAP16 * 16);
         f32x4* const wb0 = &wbuf[0][hw * 64];
+        int usrc[4];                                             // unit u = hw + 4 j -> byte offset of (s2, g, part, e) in the packed tap
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = hw + 4 * j, part = u & 1, ct = (u >> 1) & 3, s2 = u >> 3;
+            usrc[j] = __builtin_amdgcn_readfirstlane(1024 * ((s2 * 4 + (ct & 2)) * 2 + part) + 64 * (ct & 1));
+        }
 #define WT_DMA(rot_, t_)                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                          \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(wb0 + (rot_) * H3_TAP16 + 256 * j), 16, wvoff, \
-                                                     wbase + (t_) * (H3_TAP16 * 16) + j * 4096, 0, 0);
+                                                     wbase + (t_) * (H3_TAP16 * 16) + usrc[j], 0, 0);
         int t2 = 0;                                              // stream position of the NEXT tap to request
         WT_DMA(0, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
         WT_DMA(1, t2) t2 = t2 + 1 == period ? 0 : t2 + 1;
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
     // channel 16 ct + 4 kb + r of pixel (tile row 4 w + pt, column h3_row_pixel(i)).
     const int i = lane & 15, kb = lane >> 4;
     const char* const a0 = reinterpret_cast<const char*>(xin) + (4 * wv * WT_HX + h3_row_pixel(i)) * WT_PSB + h3_chunk_pos(kb, 0, 0);
-    const char* const b0 = reinterpret_cast<const char*>(&wbuf[0][0]) + wt_wrow_offset(i, kb);      // (permuted rows: wepilogue's note)
+    const char* const b0 = reinterpret_cast<const char*>(&wbuf[0][0]) + lane * 16;                  // (the helpers' DMA permuted the rows: wepilogue's note)
     int rot = 0;                                                 // buffer of the current tap = global tap % 4 (uniform)
 #ifdef H3W_PROF
     unsigned psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -275,12 +285,11 @@ __global__ __launch_bounds__(WT_THREADS, 2) void k_conv3x3_h3w(ConvArgs a, int n
 #define WT_LOAD_X(pt_, ap_, s2_)                                                                         \
             xh[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_));       \
             xl[pt_] = *reinterpret_cast<const h8*>((ap_) + (pt_) * (WT_HX * WT_PSB) + 32 * (s2_) + 16);
-            // weight fragments of (buffer, K step s2, channel-tile pair cp = g): packed fragment f = (s2 * 4 + nt) * 2 + part, 1 KiB each; the rows of
-            // tile 2 g + e sit in fragments nt = 2 g and 2 g + 1 (the lane's base, wt_wrow_offset), 64 e bytes apart
+            // weight fragments of (buffer, K step s2, channel-tile pair cp): LDS unit (s2 * 4 + ct) * 2 + part, 1 KiB each
 #define WT_LOAD_W(slot_, bw_, s2_, cp_)                                                                  \
             _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                           \
-                wh[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_)) * 2)) + 64 * c_);      \
-                wl[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_)) * 2) + 1) + 64 * c_);  \
+                wh[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2)));      \
+                wl[slot_][c_] = *reinterpret_cast<const h8*>((bw_) + 1024 * ((((s2_) * 4 + 2 * (cp_) + c_) * 2) + 1));  \
             }
             // the six MFMAs of (pixel tile pt) x (channel-tile pair cp): main += w_hi x_hi; corr += w_lo x_hi; corr += w_hi x_lo -- the order
             // of the narrow kernel (x_hi w_hi; x_hi w_lo; x_lo w_hi), the two dependent corr updates two instructions apart

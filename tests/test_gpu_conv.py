@@ -528,3 +528,45 @@ def test_ffdnet_with_its_input_and_output_stages_inside_the_first_and_last_layer
     for m in [net]:
         m.backend = 'hip_f16x3'
     assert _rel(den(x, 0), ref) <= 1e-5
+
+
+# ---- round 6: the WIDE f16x3 kernel (csrc/kernels_conv_f16x3_wide.hip: 16 x 16 tiles, 64 x 64 wave tiles, compute + helper waves) ----
+def test_wide_f16x3_kernel_is_bit_equal_to_the_narrow_one(env):
+    """Both kernels issue the same products in the same order per output value; which one a launch gets depends on its size only
+    (pnp_conv3x3_f16x3_set_variant: -1 by size, 0 narrow, 1 wide).  Every combination of activation formats x {skip, none} x {ReLU, none}
+    x {bias, none}, on shapes with ragged edges (rows / columns that are no multiple of 16, a 5-row image, one tile exactly), C = 64 /
+    128 / 256 (one, two, four chunks of input channels per item), several items per workgroup (5 x 64 x 64 on 256 compute units is
+    not enough for that: the 40-image case is): BIT-equal, and the float32 -> float32 case within the layer's bar of float64 PyTorch."""
+    torch, L, lib, D = env['torch'], env['L'], env['lib'], env['D']
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    prev = L.pnp_conv3x3_f16x3_set_variant(-1)
+    try:
+        for (nn, Cc, H, W) in ((3, 64, 37, 53), (2, 64, 16, 16), (1, 64, 5, 130), (2, 128, 40, 24), (1, 256, 17, 33), (40, 64, 96, 96)):
+            g = torch.Generator(device='cuda').manual_seed(nn * 1000 + Cc)
+            w = torch.randn(Cc, Cc, 3, 3, device='cuda', generator=g) * (2.0 / (9 * Cc)) ** 0.5
+            wp = torch.empty(9 * Cc * Cc, device='cuda')
+            lib.check(L.pnp_conv3x3_pack_f16x3(s, p(w), p(wp), Cc))
+            x = torch.randn(nn, H, W, Cc, device='cuda', generator=g)
+            k = torch.randn(nn, H, W, Cc, device='cuda', generator=g)
+            b = torch.randn(Cc, device='cuda', generator=g) * 0.1
+            xs, ks = D.split_activations(x), D.split_activations(k)
+            for fmt in range(8):
+                for skip in (0, 1):
+                    if (fmt & 2) and not skip:
+                        continue
+                    for relu, bias in ((0, 0), (1, 1)) if nn == 40 else ((0, 0), (0, 1), (1, 0), (1, 1)):
+                        out = []
+                        for variant in (0, 1):
+                            L.pnp_conv3x3_f16x3_set_variant(variant)
+                            y = torch.full_like(x, 7.0)
+                            lib.check(L.pnp_conv3x3_nhwc_f16x3_fmt(s, p(xs if fmt & 1 else x), p(wp), p(b) if bias else None,
+                                                                   p(ks if fmt & 2 else k) if skip else None, p(y), nn, Cc, H, W, relu, 1, fmt))
+                            out.append(y)
+                        assert torch.equal(out[0], out[1]), ((nn, Cc, H, W), fmt, skip, relu, bias)
+                        if fmt == 0 and skip and relu and bias:
+                            ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1)
+                                             + k.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1)
+                            assert _rel(out[1], ref) <= 6e-7, _rel(out[1], ref)
+    finally:
+        L.pnp_conv3x3_f16x3_set_variant(prev)
