@@ -190,6 +190,101 @@ def claim_stdout():
     return real
 
 
+def latency_record(device=0):
+    """The reference's OWN usage as a driver-visible number: ONE 256 x 256 slice, the committed 50 iterations (S4:83-138; S6:231-308) -- ms per
+    solve with the inputs on the device, HIP events around the loop, best of three after one warm-up solve, each with its relative L2 distance
+    from the float64 oracle on the same measurements.  BASELINE.md section 1 quotes ~0.46 s / ~0.48 s per image for the reference's ADMM_L1 /
+    ADMM_CNC and ~4.1 s for its PnP pair (log timestamps of the authors' machine: context, not a same-node comparison).
+    What bounds a one-slice solve: ONE compute unit of 256 is busy (the slice-resident kernel keeps a slice in one unit's registers; the
+    PnP forwards are 64 .. 256 tiles on 256 units, a train of 17 .. 70 launches per forward) -- latency, not bandwidth."""
+    import torch
+    import pnp_admm_cnc_mri_amd as P
+    from pnp_admm_cnc_mri_amd import denoisers as D, solvers_pnp as SP, synthetic as S, utils_pnp
+    from oracle import admm_oracle as O
+    import bench_pnp
+    rec = {'unit': 'ms per 50-iteration solve of one 256x256 slice', 'iterations': 50,
+           'reference_context': 'BASELINE.md: ~460 / ~480 ms per image (ADMM_L1 / ADMM_CNC), ~4100 ms (PNP_ADMM_CNC_DnCNN), authors\' log timestamps'}
+    dev = torch.device('cuda', device)
+    mk = S.reference_masks()
+    img, noise = S.batch(0, 1)
+
+    def best_of(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        return best
+    # plain loops through the engine (ADMM_L1: S1:171 presets; ADMM_CNC: S4:176 presets)
+    mask = mk['Q_Random30'].astype(np.uint8)
+    for key, prec in (('admm_l1_f32', 'f32'), ('admm_cnc_f32', 'f32'), ('admm_cnc_f64', 'f64')):
+        with P.Engine(256, 256, Bmax=1, device=device, precision=prec) as eng:
+            eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            eng.synthesize(img, noise, mask[None])
+            y = eng.download_y()
+
+            def solve():
+                eng.init_state()
+                if 'l1' in key:
+                    eng.admm_l1(50, 0.1, 0.015)
+                else:
+                    eng.admm_cnc(50, PRESET['alpha'], PRESET['lambda1'], PRESET['reo'], PRESET['b'])
+            ms = best_of(solve)
+            x = eng.x()[0].astype(np.float64)
+            ref = (O.admm_l1(y[0].astype(np.complex128), mask, 50, lambda1=0.1, reo=0.015) if 'l1' in key else
+                   O.admm_cnc(y[0].astype(np.complex128), mask, 50, PRESET['alpha'], PRESET['lambda1'], PRESET['reo'], PRESET['b']))
+            rec[key] = {'ms': ms, 'rel_l2_vs_oracle': float(np.linalg.norm(x - ref) / np.linalg.norm(ref)), 'path': eng.path_name}
+    # PnP: PNP_ADMM_CNC_D's loop body (solvers_pnp.py:126-133) on one slice, split-half backend, with and without HIP-graph replay of the forwards
+    for model, mname in (('ffdnet_gray', 'Q_Radial30'), ('drunet_gray', 'Q_Cartesian30')):
+        fam = D.family(model)
+        opts = SP.PRESETS['PNP_ADMM_CNC_D'][fam]
+        m = mk[mname].astype(np.uint8)
+        net, nlm, sched = D.build(model)
+        sd, _ = bench_pnp.fixture_weights(model, net, 'contractive')
+        net.load_state_dict(sd)
+        sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), 50, 49, nlm * 255., 1.0)[1]) if sched else None
+        for graph in (False, True):
+            den = D.Denoiser(model, net.eval(), nlm, sigmas=sig, backend='hip_f16x3', graph=graph).to(dev)
+            with torch.no_grad(), P.Engine(256, 256, Bmax=1, device=device) as eng:
+                eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+                eng.synthesize(img, noise, m[None])
+                z = torch.empty((1, 1, 256, 256), device=dev)
+                w = torch.empty_like(z)
+                x, s_, t_, zn = (torch.empty_like(z) for _ in range(4))
+                st = {}
+
+                def solve():
+                    eng.init_state()
+                    eng.get_state(z, w)
+                    a, b = z, zn
+                    for i in range(50):
+                        eng.dc_step(a, w, x, opts['reo'])
+                        den(a, i, out=s_)
+                        eng.cnc_combine(a, x, w, s_, t_, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
+                        den(t_, i, out=b)
+                        eng.dual_clamp(x, b, w)
+                        a, b = b, a
+                    st['x'] = x
+                ms = best_of(solve)
+                got = st['x'][0, 0].double().cpu().numpy()
+                y = eng.download_y()
+                r = {'ms': ms}
+                if not graph:                                          # (the graph replays the same kernels: one oracle loop per model)
+                    def denoise(a_, i):
+                        return den(torch.from_numpy(np.ascontiguousarray(a_, dtype=np.float32))[None, None].to(dev), i)[0, 0].cpu().numpy()
+                    ref = O.pnp_admm_cnc(y[0].astype(np.complex128), m, denoise, 50, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
+                    r['rel_l2_vs_oracle'] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+                rec['pnp_cnc_d_%s_hip_f16x3%s' % (model, '_graph' if graph else '')] = r
+        del net
+    return rec
+
+
 def pnp_record(steps=3, warmup=1, total_timeout=300):
     """BASELINE.json configs[2] (PNP_ADMM_CNC_D, FFDNet-gray, 512 slices of 256 x 256, Q_Radial30) measured by bench_pnp.py in two
     child processes -- plus configs[3]'s per-GPU shard (DRUNet-gray, Q_Cartesian30) on the f16x3 backend in a third -- AFTER this process
@@ -212,14 +307,15 @@ def pnp_record(steps=3, warmup=1, total_timeout=300):
             if left < 20:
                 raise TimeoutError('the record\'s time budget of %d s is spent' % total_timeout)
             r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_pnp.py'), '--model', model, '--batch', '512', '--steps', str(st),
-                                '--warmup', str(warmup), '--cnn-backend', backend], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                '--warmup', str(warmup), '--cnn-backend', backend, '--sustain-s', '0' if backend == 'torch' else os.environ.get('PNP_BENCH_PNP_SUSTAIN_S', '5')],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                timeout=left, cwd=ROOT)
             err = r.stderr
             j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
             rf = j['denoiser']['roofline']
             rec[key] = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'denoiser_ms_per_step': j['denoiser']['ms_per_step'],
                         'denoiser_roofline': {k: rf[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_fp32_equivalent')},
-                        'parity': j['parity'], 'weights': j['config']['weights'], 'workload': j['config']['workload'],
+                        'parity': j['parity'], 'sustained': j.get('sustained'), 'weights': j['config']['weights'], 'workload': j['config']['workload'],
                         'x_finite': j['x_finite'], 'denoiser_outputs_finite': j['denoiser_outputs_finite']}
         except subprocess.TimeoutExpired as e:
             rec[key] = {'error': 'timeout', 'stderr_tail': (e.stderr or b'').decode(errors='replace')[-600:]}
@@ -254,6 +350,8 @@ def main():
                     help='--gpus N without torchrun: seconds after which hanging rank processes are killed (exit 124)')
     ap.add_argument('--no-pnp-record', action='store_true',
                     help='skip the `pnp` sub-record (configs[2]: FFDNet PnP on the PyTorch / MIOpen backend and on the f16x3 HIP backend, configs[3] shard: DRUNet on the f16x3 backend; three child runs of bench_pnp.py, ~60 s)')
+    ap.add_argument('--no-latency-record', action='store_true',
+                    help='skip the `latency` sub-record (one 256 x 256 slice, 50 iterations: ADMM_L1, ADMM_CNC f32 / f64, PnP with FFDNet and DRUNet; ~8 s)')
     ap.add_argument('--no-l1-record', action='store_true',
                     help="skip the `l1` sub-record (ADMM_L1, configs[0]'s solver with the S1:171 presets, on the same batch; N = 1, headline configuration only)")
     ap.add_argument('--no-f64-record', action='store_true',
@@ -331,6 +429,25 @@ def main():
         del y32
     eng.init_state()
     eng.prepare_loops()                                               # per-problem tables of the loop kernels: never inside a timed region
+    # Attribution (round 6): which card, at which nominal clock, and what ITS memory system gives a plain streaming kernel with the slice
+    # kernel's access shape today (pnp_calibrate_stream, >= 0.6 s, before anything is timed) -- boxes of the pool differ by several per cent
+    # with a byte-identical kernel (10 015 -> 9 552 it/s round over round)
+    device_rec, calib = None, None
+    try:
+        import ctypes as C_
+        from pnp_admm_cnc_mri_amd import _lib as L_
+        clk, cus_ = C_.c_int(0), C_.c_int(0)
+        pci, arch = C_.create_string_buffer(32), C_.create_string_buffer(64)
+        L_.check(L_.lib().pnp_device_info(local_rank, C_.byref(clk), C_.byref(cus_), pci, 32, arch, 64))
+        device_rec = {'pci_bus_id': pci.value.decode(), 'arch': arch.value.decode(), 'clock_mhz': clk.value, 'compute_units': cus_.value}
+        if args.size == 256 and args.precision == 'f32':
+            gbs = C_.c_double(0.0)
+            L_.check(L_.lib().pnp_calibrate_stream(local_rank, B, 0.6, C_.byref(gbs)))
+            calib = {'calibration_gbs': gbs.value, 'seconds': 0.6, 'slices': B,
+                     'kernel': 'k_calibrate_stream: the slice-resident loop\'s access shape without its arithmetic (one 512-thread workgroup per '
+                               '256-KiB slice, 16 B per lane, 8 accesses in flight per wave; reads z, w, table, writes z, w)'}
+    except Exception as e:                                           # attribution never breaks the line
+        calib = {'error': repr(e)[:200]}
 
     def run(e, n):
         if args.solver == 'cnc':
@@ -576,7 +693,7 @@ def main():
                        # 0 = the iterations of a call are a loop inside ONE launch (slice-resident kernel)
                        'launches_per_iteration': eng.kernels_per_iteration,
                        'queues': eng.plan['queues'], 'slices_per_chunk': eng.plan['chunk'],
-                       'mixed_row_col_launches': bool(sched['mixed'])},
+                       'mixed_row_col_launches': bool(sched['mixed']), 'device': device_rec},
             'slice_iterations_per_s': value * B_PER_GPU,
             'hip_event_ms_per_step': ev_ms / K,
             'sustained': sustained_rec,
@@ -586,6 +703,8 @@ def main():
             'roofline': {'schema': 2,       # 2 (round 4 on): achieved / frac are PHYSICAL (PMC bytes); rounds 1-3 priced the 57 N contract bytes under the same keys
                          'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'frac_physical': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'calibration': calib,
+                         'frac_of_calibration': (achieved / calib['calibration_gbs']) if calib and calib.get('calibration_gbs') else None,
                          'bytes_per_iteration': phys_bytes, 'bytes_from': phys_kind,
                          'frac_own_algorithmic': None if own is None else own / ev_s_per_it / 1e9 / HBM_PEAK_GBS,
                          'own_algorithmic_bytes_per_iteration': own,
@@ -603,13 +722,20 @@ def main():
                                  '(slice-resident path: z, w and the Hermitian half-plane table only, the transposed field never '
                                  'leaves the compute unit; fused path: two real slices per complex FFT, Hermitian half plane).'},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.no_pnp_record and args.size == 256 and args.precision == 'f32':
-            # the children get the whole card: this process lets go of its engine, its buffers and torch's cached blocks first
+        if world == 1 and not args.no_cpu_baseline and args.size == 256 and args.precision == 'f32' and not (args.no_pnp_record and args.no_latency_record):
+            # the sub-records get the whole card: this process lets go of its engine, its buffers and torch's cached blocks first
             eng.close()
             del x_dev
             l1_rec = None
             torch.cuda.empty_cache()
-            line['pnp'] = pnp_record()
+            if not args.no_latency_record:
+                try:
+                    line['latency'] = latency_record(local_rank)
+                except Exception as e:                               # a sub-record never breaks the line
+                    line['latency'] = {'error': repr(e)[:300]}
+                torch.cuda.empty_cache()
+            if not args.no_pnp_record:
+                line['pnp'] = pnp_record()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(masks, mask_id, args.cpu_budget)
             try:

@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--cnn-batch', type=int, default=64)
     ap.add_argument('--mask', default=None)
     ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'], help='autocast throughput mode, off parity')
-    ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip', 'hip_f16x3'],
+    ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip', 'hip_f16x3', 'auto'],
                     help="hip = the plain stacks' conv3x3 layers (FFDNet, DnCNN, IRCNN) and DRUNet's 64-channel blocks on libpnpmri.so's "
                          "fp32-MFMA kernel; hip_f16x3 = the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores")
     ap.add_argument('--cnn-graph', action='store_true', help='replay each denoiser forward (<= cnn-batch slices) from a captured HIP graph')
@@ -76,6 +76,7 @@ def main():
                     help="'auto' (default): 'trained' where a trained fixture exists (ffdnet_gray), 'contractive' otherwise.  'contractive' (the 50-iteration goldens' fixture weights: a stable loop, a meaningful "
                          "parity record), 'he' (He-scaled random weights: the lines of rounds 2-4) or 'trained' (ffdnet_gray: the network trained by "
                          "oracle/train_fixture_denoiser.py -- a working denoiser's activation statistics)")
+    ap.add_argument('--sustain-s', type=float, default=0.0, help='seconds of the `sustained` sub-record (N = 1; 0 = none)')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle loop on three slices (N = 1 only; a few CPU seconds)')
     args = ap.parse_args()
 
@@ -129,6 +130,7 @@ def main():
         sig = torch.tensor(utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1])
     den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], bank=bank, cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype,
                      backend=args.cnn_backend, graph=args.cnn_graph).to(dev)
+    args.cnn_backend = den.backend                      # 'auto' resolved (denoisers.auto_backend)
     flop_per_call, flop_f16x3_part = D.forward_flops(den, H, W, dev, detail=True)     # one slice, one D(.)
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)
@@ -140,8 +142,29 @@ def main():
     eng.get_state(z, w)
     x, s, t, zn = (torch.empty_like(z) for _ in range(4))
     den_finite = torch.ones((), dtype=torch.bool, device=dev)      # every denoiser output of the run, BEFORE the clamp, stayed finite
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    t_dc = t_cnn = 0.0
+    # HIP events per iteration, READ AFTER THE LOOP: nothing on the host waits for the device between the opening and the closing sync
+    # (round 5 synchronised inside every iteration to read its events -- a host round trip per step of a kernel train whose clock is set by
+    # sustained power is not a sustained rate)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
+
+    def one_iteration(i, ev=None):
+        nonlocal z, zn, den_finite
+        if ev:
+            ev[0].record()
+        eng.dc_step(z, w, x, opts['reo'])
+        if ev:
+            ev[1].record()
+        den.select_bank(i)
+        den(z, i, out=s)
+        eng.cnc_combine(z, x, w, s, t, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
+        den(t, i, out=zn)
+        if ev:
+            ev[2].record()
+        den_finite &= torch.isfinite(s).all() & torch.isfinite(zn).all()
+        eng.dual_clamp(x, zn, w)
+        if ev:
+            ev[3].record()
+        z, zn = zn, z
     t0 = time.perf_counter()
     with torch.no_grad():
         for i in range(iters):
@@ -151,23 +174,12 @@ def main():
                     dist.barrier()
                     torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                t_dc = t_cnn = 0.0
-            ev[0].record()
-            eng.dc_step(z, w, x, opts['reo'])
-            ev[1].record()
-            den.select_bank(i)
-            den(z, i, out=s)
-            eng.cnc_combine(z, x, w, s, t, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
-            den(t, i, out=zn)
-            ev[2].record()
-            den_finite &= torch.isfinite(s).all() & torch.isfinite(zn).all()
-            eng.dual_clamp(x, zn, w)
-            ev[3].record()
-            z, zn = zn, z
-            torch.cuda.synchronize()
-            t_dc += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
-            t_cnn += ev[1].elapsed_time(ev[2])
+            one_iteration(i, evs[i])
+        torch.cuda.synchronize()
         wall = time.perf_counter() - t0              # this rank's clock stops at its own sync, before any collective
+    t_dc = sum(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs[args.warmup:])
+    t_cnn = sum(e[1].elapsed_time(e[2]) for e in evs[args.warmup:])
+    x_timed = x.clone()                               # what the parity leg checks: x after exactly `iters` iterations
 
     # Checker leg (N = 1): the oracle's PnP loop (float64 NumPy x-update, the reference's marshalling) on three slices of the run that
     # was just timed, driven by the SAME denoiser object one slice per call -- what differs from the timed run is the HIP x-update /
@@ -186,11 +198,32 @@ def main():
         with torch.no_grad():
             for b in picks:
                 ref = O.pnp_admm_cnc(y_all[b].astype(np.complex128), masks[mask_id[b]], denoise, iters, opts['alpha'], opts['lambda1'], opts['reo'], opts['b'])
-                got = x[b, 0].double().cpu().numpy()
+                got = x_timed[b, 0].double().cpu().numpy()
                 rels.append(float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
         parity = {'rel_l2_vs_oracle': rels, 'slices': picks, 'iterations': iters,
                   'oracle': 'oracle/admm_oracle.py pnp_admm_cnc (NumPy float64 x-update) driven by the same denoiser, one slice per call'}
         del y_all
+
+    # `sustained` (N = 1): the same iteration back to back for >= --sustain-s seconds, one host sync per chunk of `iters` iterations, HIP
+    # events over the span -- the rate the conv kernels hold at the clock the board settles on (the K timed steps above are ~0.1 .. 2 s
+    # from a cold process).  The state simply keeps iterating (sigma / bank index of the last step): values stay finite behind the clamp.
+    sustained = None
+    if world == 1 and args.sustain_s > 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 0
+        with torch.no_grad():
+            e0.record()
+            while True:
+                for _ in range(max(iters, 2)):
+                    one_iteration(iters - 1)
+                n += max(iters, 2)
+                e1.record()
+                e1.synchronize()
+                if e0.elapsed_time(e1) >= args.sustain_s * 1e3:
+                    break
+        span = e0.elapsed_time(e1) / 1e3
+        sustained = {'value': n / span, 'steps': n, 'span_s': span, 'ms_per_step': span * 1e3 / n,
+                     'note': 'back-to-back iterations, one host sync per %d, HIP events over the span' % max(iters, 2)}
 
     gather_ms = None
     if dist is not None:
@@ -232,7 +265,7 @@ def main():
             'config': {'workload': 'PNP_ADMM_CNC_D, %s, %d synthetic %dx%d slices per GPU, %s, S6:569-577 presets'
                                    % (args.model, B, H, W, mname), 'slices_per_gpu': B, 'path': eng.path_name,
                        'cnn_batch': args.cnn_batch, 'cnn_backend': args.cnn_backend, 'cnn_graph': bool(args.cnn_graph), 'weights': args.weights},
-            'parity': parity,
+            'parity': parity, 'sustained': sustained,
             'slice_iterations_per_s': world * K * B / wall, 'gather_ms': gather_ms,
             'per_rank': None if dist is None else {'ms_per_step': [float(v) / K * 1e3 for v in per_rank[:, 0]],
                                                    'gather_ms': [float(v) for v in per_rank[:, 3]]},
@@ -249,7 +282,7 @@ def main():
                          'note': 'PyTorch-ROCm / MIOpen fp32 convolutions (north star: PyTorch for the CNN forward)' if args.cnn_backend == 'torch' else
                                  'body layers (64 -> 64 conv3x3 + ReLU) on the fp32-MFMA implicit GEMM of libpnpmri.so (kernels_conv.hip); first / last layer on its direct kernels' if args.cnn_backend == 'hip' else
                                  'C -> C conv3x3 layers in split-half arithmetic on the f16 matrix cores (kernels_conv_f16x3.hip): roofline = the f16 matrix products really issued (3 per float32 product) against the dense f16 peak; frac_fp32_equivalent prices the float32-equivalent arithmetic against the FLOAT32 matrix peak and can exceed 1'},
-            'x_finite': bool(torch.isfinite(x).all()),
+            'x_finite': bool(torch.isfinite(x_timed).all()),
             'denoiser_outputs_finite': bool(den_finite)}) + '\n')      # taken BEFORE pnp_dual_clamp, every iteration (warm-up included)
         out.flush()
     eng.close()

@@ -29,7 +29,7 @@ def main():
     ap.add_argument('--model', default=None, help='pnp_*: fdncnn_gray | dncnn_15 | ffdnet_gray | ircnn_gray | drunet_gray (name[m] of S3:372 / S6:605)')
     ap.add_argument('--model2', default=None, help='pnp_cnc: the second DnCNN of PNP_ADMM_CNC_DnCNN (S6:617)')
     ap.add_argument('--model-zoo', default=None, help='directory of the .pth files (default: <root>/model_zoo)')
-    ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip', 'hip_f16x3'])
+    ap.add_argument('--cnn-backend', default='auto', choices=['auto', 'torch', 'hip', 'hip_f16x3'])
     ap.add_argument('--mask', type=int, default=0, help='0 Q_Random30, 1 Q_Radial30, 2 Q_Cartesian30 (k of S4:199)')
     ap.add_argument('--testset', default=None)
     ap.add_argument('--results', default='results')

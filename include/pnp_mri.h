@@ -48,6 +48,15 @@ int         pnp_abi_version(void);
 const char* pnp_last_error(void);
 /* number of HIP devices visible (0 and PNP_OK when there is none). */
 int         pnp_device_count(int* n);
+/* What a measurement needs to be attributable to a card (bench.py's `config.device`): the shader clock the driver reports (MHz), the number of
+ * compute units, the PCI bus id ("0000:05:00.0") and the architecture name ("gfx950...").  Strings are truncated to their buffers.  ABI 11. */
+int         pnp_device_info(int device, int* clock_mhz, int* compute_units, char* pci_bus_id, int pci_len, char* arch, int arch_len);
+/* CALIBRATION, not product: a streaming kernel with the slice-resident loop's ACCESS SHAPE and none of its arithmetic -- one 512-thread
+ * workgroup per "slice" (256 KiB), 16 bytes per lane, eight accesses in flight per wave; per pass it reads z, w and a table and writes z, w
+ * back (5 x 256 KiB) -- run back to back on `slices` slices for at least `seconds`; *gbs = bytes moved / HIP-event time.  What this card's
+ * memory system gives such a kernel today: bench.py prints its own fraction of 8 TB/s next to the fraction of THIS number (boxes of a pool
+ * differ by several per cent).  Allocates and frees 3 x slices x 256 KiB.  ABI 11. */
+int         pnp_calibrate_stream(int device, int slices, double seconds, double* gbs);
 
 int pnp_ctx_create(int device, int H, int W, int Bmax, pnp_ctx** out);
 int pnp_ctx_destroy(pnp_ctx* ctx);

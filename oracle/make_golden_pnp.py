@@ -285,6 +285,81 @@ def trained():
     print(json.dumps(meta['trained'], indent=1, sort_keys=True))
 
 
+def trained_trace():
+    """Round 6: TEACHER-FORCED parity at depth with a working denoiser.  A trained denoiser is locally expansive (Lipschitz ~2), so no float32
+    implementation follows the reference's 50-iteration run end to end to 1e-5 -- but ONE iteration from the reference's own state can be
+    held to it.  The pinned oracle loops (oracle/admm_oracle.py: pnp_admm_cnc, pnp_admm_l1) are driven here by the REFERENCE's CPU network
+    -- models/network_ffdnet.FFDNet built as S6:199-213 builds it, called through the scripts' own denoising_step2 (S6:18) / denoising_step1 (S3:19) -- with
+    the trained fixture weights; the run must end on the committed golden of the unmodified script (`trained_cnc_d_ffdnet_gray`, ...: that is
+    what pins the recorded states to the reference), and the states (z, w) after iterations 19 / 34 / 49 together with (x, z, w) after the
+    following iteration go to tests/golden/pnp_trace_set1_05.npz."""
+    MG.install_shims()
+    if not hasattr(np, 'int'):
+        np.int = int
+    d = MG.scratch_dir()
+    os.chdir(d)
+    os.makedirs('model_zoo')
+    torch.set_num_threads(8)
+    kj = os.path.join(MG.GOLD, 'pnp_known.json')
+    meta = json.load(open(kj))
+    for n in ('drunet_gray', 'dncnn_25', 'dncnn_15'):               # what the mains load
+        net, _, _ = D.build(n)
+        torch.save(D.contractive_state_dict(net, D.family(n), meta['known50']['seeds'][n], meta['gains50'][n]), os.path.join('model_zoo', n + '.pth'))
+    w = np.load(os.path.join(MG.GOLD, 'ffdnet_gray_trained.npz'))
+    sd = {k: torch.from_numpy(w[k]) for k in w.files}
+    torch.save(sd, os.path.join('model_zoo', 'ffdnet_gray.pth'))
+    from oracle import admm_oracle as O
+    gold = np.load(os.path.join(MG.GOLD, 'pnp50_set1_05.npz'))
+    gold_in = np.load(os.path.join(MG.GOLD, 'inputs_set1_05.npz'))
+    img_L = np.float32(gold_in['gray_u8'] / 255.)                   # util.uint2single (S6:238-239)
+    out, rec_meta = {}, {}
+    for script, fn, tag_of, cases in ((S6, 'denoising_step2', 'trained_cnc_d_ffdnet_gray%s', (('', 0, (19, 34, 49)), ('_radial30', 1, (49,)))),
+                                      (S3, 'denoising_step1', 'trained_l1_d_ffdnet_gray%s', (('', 0, (49,)),))):
+        g, _, _ = MG.run_script(script, ['--iter_num', '1'], 'Set1_dn_drunet_gray')
+        sys.path.insert(0, MG.REF)
+        from models.network_ffdnet import FFDNet as ref_net        # the REFERENCE's class (S6:199-213)
+        sys.path.remove(MG.REF)
+        model = ref_net(in_nc=1, out_nc=1, nc=64, nb=15, act_mode='R')
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        for _, v in model.named_parameters():
+            v.requires_grad = False
+        step = g[fn]
+        cnc = script is S6
+        x8 = not cnc                                               # S3:87 x8 = True (FFDNet ignores it: S3:63-65), S6:93 x8 = False
+
+        def denoise(a, i):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None]
+            with torch.no_grad():
+                return step('ffdnet_gray', t, x8, None, i, model, g['noises'], torch.device('cpu'), 15)[0, 0].numpy()
+        for suffix, k, points in cases:
+            tag = tag_of % suffix
+            mask = g['mask'][k]
+            y = np.fft.fft2(img_L) * mask + g['noises']
+            trace = tuple(sorted(set(points) | set(p_ + 1 for p_ in points)))
+            if cnc:
+                o = meta['known50'][tag + '_opts']
+                x, rec = O.pnp_admm_cnc(y, mask, denoise, 50, o['alpha'], o['lambda1'], o['reo'], o['b'], trace=trace)
+            else:
+                o = meta['known50'][tag + '_opts']
+                x, rec = O.pnp_admm_l1(y, mask, denoise, 50, o['reo'], trace=trace)
+            dev = float(np.linalg.norm(x.astype(np.float64) - gold[tag]) / np.linalg.norm(gold[tag]))
+            print('%s: the oracle loop with the reference network ends %.3g from the unmodified script\'s golden' % (tag, dev), flush=True)
+            assert dev <= 1e-6, (tag, dev)                          # pinned: the recorded states ARE the reference run's
+            rec_meta[tag] = {'end_vs_golden': dev, 'points': list(points), 'opts': o}
+            for p_ in points:
+                out['%s_it%d_z' % (tag, p_)] = rec[p_][1]
+                out['%s_it%d_w' % (tag, p_)] = rec[p_][2]
+                out['%s_it%d_x' % (tag, p_ + 1)] = rec[p_ + 1][0]
+                out['%s_it%d_z' % (tag, p_ + 1)] = rec[p_ + 1][1]
+                out['%s_it%d_w' % (tag, p_ + 1)] = rec[p_ + 1][2]     # (w + x - z is formed from the UNCLIPPED x, z: S6:305 stands before S6:306-308)
+    np.savez_compressed(os.path.join(MG.GOLD, 'pnp_trace_set1_05.npz'), **out)
+    meta['trained_trace'] = rec_meta
+    with open(kj, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print({k: v.shape for k, v in out.items()})
+
+
 def MG_sigmas(nlm, iters):
     from pnp_admm_cnc_mri_amd import utils_pnp
     return utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1]
@@ -295,6 +370,8 @@ def main():
         return extra()
     if '--fifty' in sys.argv:
         return fifty()
+    if '--trained-trace' in sys.argv:
+        return trained_trace()
     if '--trained' in sys.argv:
         return trained()
     MG.install_shims()

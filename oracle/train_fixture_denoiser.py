@@ -61,8 +61,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--patch', type=int, default=96)
     ap.add_argument('--seed', type=int, default=20261005)
-    ap.add_argument('--model', default='ffdnet_gray', choices=['ffdnet_gray', 'drunet_gray'],
-                    help='drunet_gray: for profiles/experiments/drunet_trained_check.py only (32 M parameters: nothing is committed)')
+    ap.add_argument('--model', default='ffdnet_gray', choices=['ffdnet_gray', 'drunet_gray', 'dncnn_25'],
+                    help='drunet_gray: for profiles/experiments/drunet_trained_check.py only (32 M parameters: nothing is committed); dncnn_25 (round 6): '
+                         'DnCNN-17, the x - n(x) family, trained KAIR-style at ONE noise level (25 / 255) -> tests/golden/dncnn_25_trained.npz')
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     if a.out is None:
@@ -75,12 +76,14 @@ def main():
     print('images: %.1f s' % (time.time() - t0), flush=True)
     net, _, _ = D.build(a.model)
     net = net.to(dev).train()
-    drunet = a.model == 'drunet_gray'
+    drunet, dncnn = a.model == 'drunet_gray', a.model == 'dncnn_25'
 
     def run(noisy, sigma):
-        """FFDNet takes the level as its second argument; DRUNet as a second input channel (S6:36-38)"""
+        """FFDNet takes the level as its second argument; DRUNet as a second input channel (S6:36-38); DnCNN none (one level per model)"""
         if drunet:
             return net(torch.cat((noisy, sigma.expand(-1, 1, noisy.shape[2], noisy.shape[3])), 1))
+        if dncnn:
+            return net(noisy)
         return net(noisy, sigma)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4 if a.model == 'drunet_gray' else 1e-3)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, a.steps, eta_min=2e-5)
@@ -97,6 +100,8 @@ def main():
         if step & 2:
             clean = clean.transpose(2, 3)
         sigma = torch.rand((a.batch, 1, 1, 1), device=dev, generator=g) * (75.0 / 255.0)
+        if dncnn:
+            sigma = torch.full_like(sigma, 25.0 / 255.0)
         noisy = clean + sigma * torch.randn(clean.shape, device=dev, generator=g)
         loss = torch.nn.functional.l1_loss(run(noisy, sigma), clean)
         opt.zero_grad(set_to_none=True)
@@ -109,7 +114,7 @@ def main():
     net.eval()
     rec = {'seed': a.seed, 'steps': a.steps, 'batch': a.batch, 'patch': a.patch, 'final_l1': float(np.mean(losses[-200:])), 'held_out_psnr': {}}
     with torch.no_grad():
-        for s in (15, 25, 50):
+        for s in ((25,) if dncnn else (15, 25, 50)):
             sig = torch.full((held.shape[0], 1, 1, 1), s / 255.0, device=dev)
             noisy = held[:, None] + sig * torch.randn(held[:, None].shape, device=dev, generator=g)
             den = run(noisy, sig)

@@ -21,6 +21,8 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); mirrors include/pnp_mri.h one to one
 SIGNATURES = {
     'pnp_abi_version': (C.c_int, []),
+    'pnp_device_info': (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
+    'pnp_calibrate_stream': (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     'pnp_last_error': (C.c_char_p, []),
     'pnp_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'pnp_ctx_create': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ctx_p)]),

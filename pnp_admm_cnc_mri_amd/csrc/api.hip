@@ -185,6 +185,51 @@ int pnp_device_count(int* n) {
     return PNP_OK;
 }
 
+int pnp_device_info(int device, int* clock_mhz, int* compute_units, char* pci_bus_id, int pci_len, char* arch, int arch_len) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (clock_mhz) *clock_mhz = p.clockRate / 1000;
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (pci_bus_id && pci_len > 0) { pci_bus_id[0] = 0; HIPCHK(hipDeviceGetPCIBusId(pci_bus_id, pci_len, device)); }
+    if (arch && arch_len > 0) { snprintf(arch, (size_t)arch_len, "%s", p.gcnArchName); }
+    return PNP_OK;
+}
+
+int pnp_calibrate_stream(int device, int slices, double seconds, double* gbs) {
+    if (!gbs || slices < 1 || slices > 4096 || !(seconds > 0.0) || seconds > 30.0) return fail(PNP_E_ARG, "pnp_calibrate_stream: 1 <= slices <= 4096, 0 < seconds <= 30, gbs non-null");
+    HIPCHK(hipSetDevice(device));
+    const size_t bytes = (size_t)slices << 18;
+    float *z = nullptr, *w = nullptr, *y = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PNP_OK;
+    double moved = 0.0, ms_total = 0.0;
+#define CAL(x) do { if (rc == PNP_OK) { hipError_t e_ = (x); if (e_ != hipSuccess) rc = fail(PNP_E_HIP, "pnp_calibrate_stream: %s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    CAL(hipMalloc((void**)&z, bytes)); CAL(hipMalloc((void**)&w, bytes)); CAL(hipMalloc((void**)&y, bytes));
+    CAL(hipMemset(z, 0, bytes)); CAL(hipMemset(w, 0, bytes)); CAL(hipMemset(y, 0, bytes));
+    CAL(hipEventCreate(&e0)); CAL(hipEventCreate(&e1));
+    const int passes = 50;
+    CAL(launch_calibrate_stream(nullptr, z, w, y, slices, 5));                           // warm-up
+    CAL(hipDeviceSynchronize());
+    while (rc == PNP_OK && ms_total < seconds * 1e3) {
+        CAL(hipEventRecord(e0, nullptr));
+        CAL(launch_calibrate_stream(nullptr, z, w, y, slices, passes));
+        CAL(hipEventRecord(e1, nullptr));
+        CAL(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CAL(hipEventElapsedTime(&ms, e0, e1));
+        ms_total += ms;
+        moved += 5.0 * 262144.0 * slices * passes;
+    }
+#undef CAL
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (z) (void)hipFree(z);
+    if (w) (void)hipFree(w);
+    if (y) (void)hipFree(y);
+    if (rc == PNP_OK) *gbs = moved / (ms_total * 1e-3) / 1e9;
+    return rc;
+}
+
 static int ctx_create_any(int device, int H, int W, int Bmax, pnp_ctx** out, bool f64) {
     if (!out) return fail(PNP_E_ARG, "pnp_ctx_create: out is null");
     *out = nullptr;

@@ -73,6 +73,8 @@ hipError_t upload_gauss();
 template <typename X> hipError_t launch_ssim(hipStream_t s, const X* x, const uint8_t* gt, double* partial /*[B][tiles]*/, int B, int H, int W);
 hipError_t launch_widen(hipStream_t s, const float* in, double* out, size_t n);      // float -> double, n % 4 == 0
 
+// calibration (pnp_calibrate_stream): the slice-resident loop's access shape without its arithmetic, `passes` passes over `slices` slices of 256 KiB
+hipError_t launch_calibrate_stream(hipStream_t s, float* z, float* w, const float* y, int slices, int passes);
 // optional HIP backend of the denoisers' 64-channel conv3x3 body layers (kernels_conv.hip); activations NHWC float32
 hipError_t launch_conv_pack_w(hipStream_t s, const float* w_oihw /*[64][64][3][3]*/, float* wfrag /*36 864 floats*/);
 hipError_t launch_conv3x3_c64(hipStream_t s, const float* x, const float* wfrag, const float* bias, const float* skip,

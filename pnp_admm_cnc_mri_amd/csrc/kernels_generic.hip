@@ -843,4 +843,36 @@ hipError_t launch_widen(hipStream_t s, const float* in, double* out, size_t n) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Calibration (pnp_calibrate_stream, include/pnp_mri.h): the slice-resident kernel's ACCESS SHAPE without its arithmetic (profiles/micro/
+// slice_stride.hip, round 3, moved into the library in round 6 so that bench.py can print what THIS card's memory system gives such a
+// kernel next to the kernel's own rate).  One 512-thread workgroup per 256-KiB slice; per pass: read z, w and a table, write z, w back in
+// place, 16 bytes per lane, eight accesses of each array in flight per wave.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_calibrate_stream(float4* z, float4* w, const float4* y, int passes) {
+    const size_t base = (size_t)blockIdx.x * 16384;
+    float4* zs = z + base;
+    float4* ws = w + base;
+    const float4* ys = y + base;
+    const int tid = threadIdx.x;
+    for (int it = 0; it < passes; ++it)
+        for (int g = 0; g < 4; ++g) {
+            float4 a[8], b[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = tid + 512 * (8 * g + u); a[u] = zs[i]; b[u] = ws[i]; c[u] = ys[i]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = tid + 512 * (8 * g + u);
+                zs[i] = make_float4(a[u].x + c[u].x * 1e-9f, a[u].y + c[u].y * 1e-9f, a[u].z + c[u].z * 1e-9f, a[u].w + c[u].w * 1e-9f);
+                ws[i] = make_float4(b[u].x - c[u].x * 1e-9f, b[u].y - c[u].y * 1e-9f, b[u].z - c[u].z * 1e-9f, b[u].w - c[u].w * 1e-9f);
+            }
+        }
+}
+
+hipError_t launch_calibrate_stream(hipStream_t s, float* z, float* w, const float* y, int slices, int passes) {
+    hipLaunchKernelGGL(k_calibrate_stream, dim3((unsigned)slices), dim3(512), 0, s, reinterpret_cast<float4*>(z), reinterpret_cast<float4*>(w),
+                       reinterpret_cast<const float4*>(y), passes);
+    return hipGetLastError();
+}
+
 }  // namespace pnp

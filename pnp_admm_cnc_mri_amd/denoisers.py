@@ -16,6 +16,7 @@ plus the dispatch `denoising_step` (S6:18-67 == S3:19-68), the inference wrapper
 reference ships no weights: model_zoo/README.md).
 """
 import hashlib
+import logging
 import math
 
 import numpy as np
@@ -425,11 +426,11 @@ class UNetRes(nn.Module):
                 and self.m_head.in_channels <= 8 and self.m_head.out_channels == 64 and _plain3x3(self.m_tail)
                 and self.m_tail.in_channels == 64 and self.m_tail.out_channels <= 4)
 
-    def hip_covers(self, H=None, W=None):
+    def hip_covers(self, H=None, W=None, backend=None):
         """True when EVERY convolution of the U-Net runs on libpnpmri.so under backend 'hip_f16x3': first / last layer, all residual
         blocks, the three 2 x 2 stride-2 convolutions and the three 2 x 2 transposed ones (csrc/kernels_pix2x2_f16x3.hip) -- such a
         forward makes no MIOpen call at all.  H, W (if given) must survive three halvings."""
-        if self.backend != 'hip_f16x3' or (H is not None and (H % 8 or W % 8)):
+        if (backend or self.backend) != 'hip_f16x3' or (H is not None and (H % 8 or W % 8)):      # backend=: "would it, under that backend?" (auto_backend)
             return False
         if not (_plain3x3(self.m_head) and self.m_head.in_channels <= 8 and self.m_head.out_channels == 64 and self.m_head.bias is None
                 and _plain3x3(self.m_tail) and self.m_tail.in_channels == 64 and self.m_tail.out_channels <= 4):
@@ -751,6 +752,36 @@ def forward_flops(den, H, W, device, detail=False):
     return (2 * macs[0], 2 * macs[1]) if detail else 2 * macs[0]
 
 
+def auto_backend(model, device=None, bank=None, cnn_dtype=None):
+    """What `cnn_backend='auto'` (the entry points' default since round 6) resolves to: ('hip_f16x3' | 'torch', reason).
+    'hip_f16x3' -- the split-half matrix-core kernels of libpnpmri.so, held to the same goldens and bars as the PyTorch / MIOpen backend at
+    every run length (tests/test_gpu_pnp.py) -- when (a) the device is a gfx950 part, (b) EVERY convolution of the network is one the
+    library takes (hip_covers_stack / UNetRes.hip_covers: otherwise part of the forward would still be MIOpen's), (c) every weight -- of
+    every model of an IRCNN bank -- is finite and inside the half range, (d) float32 arithmetic is asked for.  'torch' otherwise."""
+    if cnn_dtype not in (None, 'fp32'):
+        return 'torch', 'cnn_dtype=%s is a PyTorch autocast mode' % cnn_dtype
+    dev = torch.device(device if device is not None else 'cuda')
+    if dev.type != 'cuda' or not torch.cuda.is_available():
+        return 'torch', 'no HIP device'
+    arch = getattr(torch.cuda.get_device_properties(dev), 'gcnArchName', '')
+    if not arch.startswith('gfx950'):
+        return 'torch', 'device is %s, the kernels are built for gfx950' % (arch or 'unknown')
+    if isinstance(model, UNetRes):
+        covered = model.hip_covers(backend='hip_f16x3')
+    elif isinstance(model, _PlainStack):
+        covered = hip_covers_stack(model.model)
+    else:
+        covered = False
+    if not covered:
+        return 'torch', 'the network has layers libpnpmri.so does not take'
+    sds = [model.state_dict()] + ([bank[k] for k in bank] if bank else [])
+    for sd in sds:
+        for k, v in sd.items():
+            if torch.is_floating_point(v) and (not bool(torch.isfinite(v).all()) or float(v.abs().max()) > 65504.):
+                return 'torch', 'weight %s lies outside the half range' % k
+    return 'hip_f16x3', 'every convolution on libpnpmri.so (split-half f16 matrix-core kernels), weights inside the half range'
+
+
 class Denoiser:
     """`denoising_step2` (S6:18-67) == `denoising_step1` (S3:19-68) bound to one model: maps a
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
@@ -770,8 +801,11 @@ class Denoiser:
         self._graphs = {}
         self._sig_static = None
         self._in_graph = False
+        if backend == 'auto':
+            backend, why = auto_backend(model, None, bank, cnn_dtype)
+            logging.getLogger('pnp_admm_cnc_mri_amd').info('cnn_backend=auto -> %s (%s)', backend, why)
         if backend not in ('torch',) + HIP_BACKENDS:
-            raise ValueError("backend must be 'torch', 'hip' or 'hip_f16x3'")
+            raise ValueError("backend must be 'auto', 'torch', 'hip' or 'hip_f16x3'")
         if backend in HIP_BACKENDS and cnn_dtype not in (None, 'fp32'):
             raise ValueError("backend='%s' takes and returns float32 only" % backend)
         self.name, self.fam = model_name, family(model_name)

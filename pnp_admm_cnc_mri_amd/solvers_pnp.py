@@ -19,13 +19,19 @@ save_E=, device=, return_info=  as in solvers.py, plus
     miopen_find='auto'      'auto': torch.backends.cudnn.benchmark is switched on around the CNN forward passes of conv batches
                             of >= 16 images and restored afterwards (a process-global flag: INTEGRATION.md section 4);
                             False / True: leave the caller's setting alone / force a find for every forward
-    cnn_backend='torch'     'torch': the whole CNN forward in PyTorch-ROCm / MIOpen (north star); 'hip': the 64 -> 64 conv3x3 + ReLU
+    cnn_backend='auto'      'auto' (default since round 6): 'hip_f16x3' when the device is gfx950, every convolution of the network is one
+                            libpnpmri.so takes and the weights lie inside the half range, else 'torch' -- one log line says which and why
+                            (denoisers.auto_backend); 'torch': the whole CNN forward in PyTorch-ROCm / MIOpen (north star); 'hip': the 64 -> 64 conv3x3 + ReLU
                             body layers of DnCNN / FDnCNN / FFDNet on libpnpmri.so's fp32 matrix-core kernel (exact f32
                             arithmetic, ~1e-6 from MIOpen's results; first and last layer on its direct kernels);
                             'hip_f16x3': the same with the 64 -> 64 layers in split-half arithmetic on the f16 matrix cores
                             (float32 operands as two halves, exact products, float32 accumulation: float32-level results,
                             2.3 x the float32 kernel's rate; operands must lie within the half range)
     return_device=False     True: `out` is one torch tensor [B,H,W] on the device instead of the 22-slot list of host arrays (solvers.py)
+    state0=None, iter_start=0   (PNP_ADMM_CNC_D, PNP_ADMM_L1_D) resume the loop: state0 = (z, w) arrays [B,H,W] as they stand AFTER iteration
+                            iter_start, the loop then runs iterations iter_start .. iter_num - 1 (sigma schedule, bank switch and x8 mode of
+                            those indices).  With return_info=True the final (z, w) come back as info['z'], info['w'].  What the
+                            teacher-forced parity tests use: one iteration from the reference's own state (tests/test_gpu_pnp.py)
     cnn_graph=False         True: a denoiser forward of at most cnn_batch slices is captured once per shape into a HIP graph and replayed
                             (the reference's one-slice calls: a forward is a train of short launches; FFDNet 0.50 -> see DESIGN.md 4.8)
 """
@@ -56,7 +62,7 @@ PRESETS = {
 
 
 def _load_model(model_name, model, model_zoo, iter_num, noises, x8, cnn_batch, device, cnn_dtype=None, miopen_find='auto',
-                cnn_backend='torch', cnn_graph=False):
+                cnn_backend='auto', cnn_graph=False):
     """The model-zoo switch of S6:129-217: build by name, load weights, eval, no grad, to device."""
     import torch
     net, nlm, scheduled = D.build(model_name)
@@ -96,6 +102,15 @@ def _device_state(torch, eng, B, H, W, dev):
     return x, z, w
 
 
+def _resume(torch, z, w, state0, dev):
+    """state0 = (z, w) [B,H,W] host arrays -> the loop's device tensors (float32, as S6:277-285 hands them to the network)"""
+    if state0 is None:
+        return
+    z0, w0 = state0
+    z.copy_(torch.from_numpy(np.ascontiguousarray(z0, dtype=np.float32)).reshape(z.shape).to(dev))
+    w.copy_(torch.from_numpy(np.ascontiguousarray(w0, dtype=np.float32)).reshape(w.shape).to(dev))
+
+
 def _finish_pnp(torch, job, eng, x, extra, return_device=False):
     """S6:314-351: img_E = uint8(round(x*255)); metrics on the quantised image.  return_device: `out` is the device tensor [B,H,W]
     (solvers.py), no host copy of the reconstructions."""
@@ -107,8 +122,8 @@ def _finish_pnp(torch, job, eng, x, extra, return_device=False):
 
 def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                    testset_name='Set1', results='results', save_E=None, device=None, return_info=False,
-                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False,
-                   **PNP_ADMM_CNC_D_opts):
+                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False,
+                   state0=None, iter_start=0, **PNP_ADMM_CNC_D_opts):
     """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
     import torch
     alpha = PNP_ADMM_CNC_D_opts.get('alpha', 0.4)          # S6:85-89
@@ -124,10 +139,11 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
+        _resume(torch, z, w, state0, dev)
         s = torch.empty_like(z)
         t = torch.empty_like(z)
         z_new = torch.empty_like(z)
-        for i in range(iter_num):                                             # S6:262
+        for i in range(iter_start, iter_num):                                 # S6:262
             eng.dc_step(z, w, x, reo)                                         # S6:266-271
             den.select_bank(i)                                                # S6:289-298
             den(z, i, out=s)                                                  # S6:300
@@ -137,13 +153,15 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
             z, z_new = z_new, z
         torch.cuda.current_stream(dev).synchronize()
         out, psnr1, info = _finish_pnp(torch, job, eng, x, 'alpha: ({:.3f}), '.format(alpha), return_device)
+        if return_info:
+            info['z'], info['w'] = z.reshape(B, H, W).cpu().numpy(), w.reshape(B, H, W).cpu().numpy()
     return (out, psnr1, info) if return_info else (out, psnr1)
 
 
 def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
                        testsets='testsets', testset_name='Set1', results='results', save_E=None, device=None,
                        return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
-                       cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False, **opts):
+                       cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False, **opts):
     """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
     `faithful_model2_path`: the reference loads model_path1 into BOTH nets (S6:435) although it logs
     path 2; True reproduces that, False loads model_name2's own weights."""
@@ -180,8 +198,8 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
 
 def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                   testset_name='Set1', results='results', save_E=None, device=None, return_info=False,
-                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='torch', cnn_graph=False, return_device=False,
-                  **PNP_ADMM_L1_D_opts):
+                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False,
+                  state0=None, iter_start=0, **PNP_ADMM_L1_D_opts):
     """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
     import torch
     iter_num = PNP_ADMM_L1_D_opts.get('iter_num', 20)      # S3:83-84
@@ -196,8 +214,9 @@ def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, t
     with torch.cuda.device(dev), torch.no_grad(), job.open_engine(torch.cuda.current_stream(dev).cuda_stream) as eng:
         B, H, W = job.B, job.H, job.W
         x, z, w = _device_state(torch, eng, B, H, W, dev)
+        _resume(torch, z, w, state0, dev)
         t = torch.empty_like(z)
-        for i in range(iter_num):                                             # S3:255
+        for i in range(iter_start, iter_num):                                 # S3:255
             eng.dc_step(z, w, x, reo)                                         # S3:259-264
             den.select_bank(i)
             eng.add(x, w, t)                                                  # x + w
@@ -205,4 +224,6 @@ def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, t
             eng.dual_clamp(x, z, w)                                           # S3:293-296
         torch.cuda.current_stream(dev).synchronize()
         out, _, info = _finish_pnp(torch, job, eng, x, '', return_device)
+        if return_info:
+            info['z'], info['w'] = z.reshape(B, H, W).cpu().numpy(), w.reshape(B, H, W).cpu().numpy()
     return (out, info) if return_info else out

@@ -302,3 +302,11 @@ def test_oracle_pnp_loop_with_the_trained_network_vs_the_unmodified_reference(go
     o = meta['trained_cnc_d_ffdnet_gray_it%d_opts' % n_it]
     x = O.pnp_admm_cnc(y, mask, denoise, n_it, o['alpha'], o['lambda1'], o['reo'], o['b'])
     assert rel_l2(x, gold['trained_cnc_d_ffdnet_gray_it%d' % n_it]) <= 2e-6, rel_l2(x, gold['trained_cnc_d_ffdnet_gray_it%d' % n_it])
+
+
+def test_auto_backend_without_a_hip_device_is_torch():
+    """cnn_backend='auto' (the entry points' default): no HIP device here -> the PyTorch backend, with the reason; autocast modes likewise"""
+    net, _, _ = D.build('ffdnet_gray')
+    be, why = D.auto_backend(net)
+    assert be == 'torch' and 'HIP' in why
+    assert D.auto_backend(net, cnn_dtype='bf16')[0] == 'torch'

@@ -395,3 +395,62 @@ def test_pnp_with_a_trained_ffdnet_at_the_presets_fifty_iterations(env50, golden
     assert rel_l2(out[0], ref) <= 3e-2, rel_l2(out[0], ref)          # measured 7e-4 .. 1e-2, all three backends alike (the loop is expansive by now)
     psnr = O.calculate_psnr(np.round(out[0].astype(np.float64) * 255), golden_inputs['gray'])
     assert abs(psnr - float(env50['known50'][tag].split('PSNR:')[1].split('dB')[0])) <= 0.01, (psnr, env50['known50'][tag])
+
+# ----------------------------------------------------------------------------------------------
+# Round 6: TEACHER-FORCED parity at depth with the trained denoiser.  The loop is expansive by iteration 20, so the end-to-end bars above widen
+# with the iteration count -- but ONE iteration from the reference's own state can be held tight at any depth.  tests/golden/pnp_trace_set1_05.npz
+# (oracle/make_golden_pnp.py --trained-trace): the pinned oracle loop driven by the REFERENCE's CPU FFDNet through the scripts' own
+# denoising_step, which ends bit-equal on the unmodified scripts' 50-iteration goldens; recorded: (z, w) after iterations 19 / 34 / 49 and
+# (x, z, w) after the next one.  Here the entry points resume from that state (state0=, iter_start=) and run exactly
+# one iteration of their loop body on each CNN backend: x, z, w of iteration 20 / 35 / 50 within 2e-6 of the reference's.
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def trace50():
+    return np.load(os.path.join(GOLD, 'pnp_trace_set1_05.npz'))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('tag,k', [('trained_cnc_d_ffdnet_gray', 19), ('trained_cnc_d_ffdnet_gray', 34), ('trained_cnc_d_ffdnet_gray', 49),
+                                   ('trained_cnc_d_ffdnet_gray_radial30', 49), ('trained_l1_d_ffdnet_gray', 49)])
+def test_one_iteration_from_the_references_state_at_depth(env50, trace50, golden_inputs, tag, k, backend, tmp_path):
+    from conftest import weights_trained
+    opts = dict(env50['known50'][tag + '_opts'])
+    opts['iter_num'] = k + 1                                       # the loop runs iteration index k only
+    mask = golden_inputs['masks']['Q_Radial30' if tag.endswith('radial30') else 'Q_Random30'].astype(np.float64)
+    z0, w0 = trace50['%s_it%d_z' % (tag, k)], trace50['%s_it%d_w' % (tag, k)]
+    kw = dict(images=golden_inputs['gray'][None], model=weights_trained(), results=str(tmp_path), cnn_backend=backend,
+              state0=(z0[None], w0[None]), iter_start=k, return_info=True)
+    if 'l1_d' in tag:
+        out, info = env50['S'].PNP_ADMM_L1_D('ffdnet_gray', mask, golden_inputs['noises'], **kw, **opts)
+    else:
+        out, _, info = env50['S'].PNP_ADMM_CNC_D('ffdnet_gray', mask, golden_inputs['noises'], **kw, **opts)
+    x1, z1, w1 = (trace50['%s_it%d_%s' % (tag, k + 1, v)] for v in 'xzw')
+    got = {'x': out[0], 'z': info['z'][0], 'w': info['w'][0]}
+    for name, ref in (('x', x1), ('z', z1), ('w', w1)):
+        assert rel_l2(got[name], ref) <= 2e-6, (tag, k, backend, name, rel_l2(got[name], ref))
+
+
+def test_the_default_cnn_backend_is_the_library_where_it_covers_the_network(env, golden_inputs, tmp_path, caplog):
+    """cnn_backend='auto' (default since round 6; S6:79 has no such keyword -- a user who swaps the import gets the fast path): on this gfx950
+    box FFDNet, DnCNN-17, FDnCNN, IRCNN and DRUNet resolve to 'hip_f16x3' with one log line; a weight beyond the half range, or an autocast
+    mode, resolves to 'torch' with the reason; and the default call equals the explicit cnn_backend='hip_f16x3' call bit for bit."""
+    import logging
+    torch, D, S = env['torch'], env['D'], env['S']
+    for name in ('ffdnet_gray', 'dncnn_25', 'fdncnn_gray', 'ircnn_gray', 'drunet_gray'):
+        net, _, _ = D.build(name)
+        be, why = D.auto_backend(net)
+        assert be == 'hip_f16x3', (name, why)
+    net, _, _ = D.build('ffdnet_gray')
+    with torch.no_grad():
+        next(p_ for n_, p_ in net.named_parameters() if n_.endswith('weight'))[0, 0, 0, 0] = 1e5
+    assert D.auto_backend(net)[0] == 'torch' and 'half range' in D.auto_backend(net)[1]
+    net, _, _ = D.build('ffdnet_gray')
+    assert D.auto_backend(net, cnn_dtype='bf16')[0] == 'torch'
+    sd = D.seeded_state_dict(net, 7)
+    mask = golden_inputs['masks']['Q_Radial30'].astype(np.float64)
+    kw = dict(images=golden_inputs['gray'][None], model=sd, results=str(tmp_path), alpha=0.9, iter_num=3, lambda1=1.35, reo=0.45, b=0.3)
+    with caplog.at_level(logging.INFO, logger='pnp_admm_cnc_mri_amd'):
+        dflt, _ = S.PNP_ADMM_CNC_D('ffdnet_gray', mask, golden_inputs['noises'], **kw)
+    assert any('cnn_backend=auto -> hip_f16x3' in r.getMessage() for r in caplog.records)
+    expl, _ = S.PNP_ADMM_CNC_D('ffdnet_gray', mask, golden_inputs['noises'], cnn_backend='hip_f16x3', **kw)
+    assert np.array_equal(dflt[0], expl[0])
