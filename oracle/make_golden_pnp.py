@@ -360,6 +360,68 @@ def trained_trace():
     print({k: v.shape for k, v in out.items()})
 
 
+def trained_dncnn():
+    """Round 6: a TRAINED DnCNN-17 -- the x - n(x) family (models/network_dncnn.py:36-67), trained KAIR-style at sigma = 25 / 255 by
+    oracle/train_fixture_denoiser.py --model dncnn_25 (tests/golden/dncnn_25_trained.npz) -- under the unmodified scripts: PNP_ADMM_CNC_DnCNN at
+    the S6:571 preset (the reference loads model 1's file into both networks, S6:435) and PNP_ADMM_L1_D('dncnn_15') at the S3:341 preset, at 2 / 5
+    / 10 iterations (where float32 can hold 1e-5) and, for the record and the PSNR line, the pair's own 50.  Appended to pnp50_set1_05.npz."""
+    MG.install_shims()
+    if not hasattr(np, 'int'):
+        np.int = int
+    d = MG.scratch_dir()
+    os.chdir(d)
+    os.makedirs('model_zoo')
+    torch.set_num_threads(8)
+    kj = os.path.join(MG.GOLD, 'pnp_known.json')
+    meta = json.load(open(kj))
+    net, _, _ = D.build('drunet_gray')                               # what the mains load besides the DnCNN files
+    torch.save(D.contractive_state_dict(net, 'drunet', meta['known50']['seeds']['drunet_gray'], meta['gains50']['drunet_gray']), os.path.join('model_zoo', 'drunet_gray.pth'))
+    w = np.load(os.path.join(MG.GOLD, 'dncnn_25_trained.npz'))
+    net, _, _ = D.build('dncnn_25')
+    sd = {k: torch.from_numpy(w[k]) for k in net.state_dict()}
+    net.load_state_dict(sd, strict=True)
+    for n in ('dncnn_25', 'dncnn_15'):
+        torch.save(sd, os.path.join('model_zoo', n + '.pth'))
+    npz = os.path.join(MG.GOLD, 'pnp50_set1_05.npz')
+    arrays = dict(np.load(npz))
+    known = meta['known50']
+
+    def line(lines):
+        return [l for l in lines if 'PSNR' in l and '05.png' in l][-1]
+    g, _, _ = MG.run_script(S6, ['--iter_num', '1'], 'Set1_dn_drunet_gray')
+    for n_it in (2, 5, 10, 50):
+        opts = dict(g['PNP_ADMM_CNC_DnCNN_opts'], iter_num=n_it)
+        cap = MG._Capture('Set1_dn_dncnn_25_dncnn_15')
+        with contextlib.redirect_stdout(io.StringIO()):
+            o, _ = g['PNP_ADMM_CNC_DnCNN']('dncnn_25', 'dncnn_15', g['mask'][0], g['noises'], **opts)
+        tag = 'trained_cnc_dncnn_pair' + ('' if n_it == 50 else '_it%d' % n_it)
+        arrays[tag] = np.asarray(o[0], np.float32)
+        known[tag] = line(cap.lines)
+        known[tag + '_opts'] = {kk: float(v) for kk, v in opts.items()}
+        known[tag + '_sum'] = float(arrays[tag].astype(np.float64).sum())
+        print(tag, known[tag], flush=True)
+    g, _, _ = MG.run_script(S3, ['--iter_num', '1'], 'Set1_dn_drunet_gray')
+    for n_it in (2, 5, 10):
+        opts = dict(g['PNP_ADMM_L1_D_opts2'], iter_num=n_it)
+        cap = MG._Capture('Set1_dn_dncnn_15')
+        with contextlib.redirect_stdout(io.StringIO()):
+            o = g['PNP_ADMM_L1_D']('dncnn_15', g['mask'][0], g['noises'], **opts)
+        tag = 'trained_l1_d_dncnn_15_it%d' % n_it
+        arrays[tag] = np.asarray(o[0], np.float32)
+        known[tag] = line(cap.lines)
+        known[tag + '_opts'] = {kk: float(v) for kk, v in opts.items()}
+        known[tag + '_sum'] = float(arrays[tag].astype(np.float64).sum())
+        print(tag, known[tag], flush=True)
+    tj = os.path.join(ROOT, 'gpurun_out', 'dncnn_25_trained.json')
+    meta.setdefault('trained_dncnn', {})
+    if os.path.exists(tj):
+        meta['trained_dncnn']['training'] = json.load(open(tj))
+    meta['trained_dncnn']['weights'] = 'tests/golden/dncnn_25_trained.npz (oracle/train_fixture_denoiser.py --model dncnn_25)'
+    np.savez_compressed(npz, **arrays)
+    with open(kj, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def MG_sigmas(nlm, iters):
     from pnp_admm_cnc_mri_amd import utils_pnp
     return utils_pnp.get_rho_sigma(max(0.255 / 255., nlm), iters, 49, nlm * 255., 1.0)[1]
@@ -370,6 +432,8 @@ def main():
         return extra()
     if '--fifty' in sys.argv:
         return fifty()
+    if '--trained-dncnn' in sys.argv:
+        return trained_dncnn()
     if '--trained-trace' in sys.argv:
         return trained_trace()
     if '--trained' in sys.argv:

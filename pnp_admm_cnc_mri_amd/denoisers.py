@@ -368,9 +368,9 @@ class _ResBlock(nn.Module):
         self.res = nn.Sequential(nn.Conv2d(nc, nc, 3, 1, 1, bias=False), nn.ReLU(inplace=True),
                                  nn.Conv2d(nc, nc, 3, 1, 1, bias=False))
 
-    def hip_ok(self):
-        return (self.backend in HIP_BACKENDS and _hip_body_ok(self.res[0], _hip_math(self.backend))
-                and _hip_body_ok(self.res[2], _hip_math(self.backend)))
+    def hip_ok(self, backend=None):
+        be = backend or self.backend                                   # backend=: "would it, under that backend?" (auto_backend)
+        return be in HIP_BACKENDS and _hip_body_ok(self.res[0], _hip_math(be)) and _hip_body_ok(self.res[2], _hip_math(be))
 
     def forward_nhwc(self, xn, in_split=False, out_split=False):
         """the block on a contiguous [n][H][W][C] tensor, on libpnpmri.so (hip_ok() must hold).  Under 'hip_f16x3' the tensor between
@@ -439,15 +439,15 @@ class UNetRes(nn.Module):
             d = seq[-1]
             if not (isinstance(d, nn.Conv2d) and d.kernel_size == (2, 2) and d.stride == (2, 2) and d.padding == (0, 0) and d.bias is None
                     and d.groups == 1 and d.dilation == (1, 1) and d.out_channels == 2 * d.in_channels and d.in_channels % 64 == 0 and d.in_channels <= 1024
-                    and all(isinstance(m, _ResBlock) and m.hip_ok() for m in seq[:-1])):
+                    and all(isinstance(m, _ResBlock) and m.hip_ok(backend) for m in seq[:-1])):
                 return False
         for seq in (self.m_up3, self.m_up2, self.m_up1):
             u = seq[0]
             if not (isinstance(u, nn.ConvTranspose2d) and u.kernel_size == (2, 2) and u.stride == (2, 2) and u.padding == (0, 0) and u.bias is None
                     and u.output_padding == (0, 0) and u.groups == 1 and u.dilation == (1, 1) and 2 * u.out_channels == u.in_channels
-                    and u.in_channels % 128 == 0 and u.in_channels <= 1024 and all(isinstance(m, _ResBlock) and m.hip_ok() for m in seq[1:])):
+                    and u.in_channels % 128 == 0 and u.in_channels <= 1024 and all(isinstance(m, _ResBlock) and m.hip_ok(backend) for m in seq[1:])):
                 return False
-        return all(isinstance(m, _ResBlock) and m.hip_ok() for m in self.m_body)
+        return all(isinstance(m, _ResBlock) and m.hip_ok(backend) for m in self.m_body)
 
     def _forward_f16x3(self, x0):
         """models/network_unet.py:123-136 with every tensor NHWC and every layer on libpnpmri.so; the four skip sums are formed inside the

@@ -76,6 +76,6 @@ def weights_trained(name='ffdnet_gray'):
     """The TRAINED fixture network (oracle/train_fixture_denoiser.py: FFDNet-gray trained KAIR-style on seeded synthetic images for a few
     minutes; tests/golden/ffdnet_gray_trained.npz) as a state_dict -- the weights behind the 'trained_*' goldens of pnp50_set1_05.npz."""
     import torch
-    assert name == 'ffdnet_gray'
-    w = np.load(os.path.join(GOLD, 'ffdnet_gray_trained.npz'))
+    assert name in ('ffdnet_gray', 'dncnn_25')                     # dncnn_25 (round 6): DnCNN-17, the x - n(x) family, trained at sigma = 25 / 255
+    w = np.load(os.path.join(GOLD, name + '_trained.npz'))
     return {k: torch.from_numpy(w[k]) for k in w.files}

@@ -310,3 +310,27 @@ def test_auto_backend_without_a_hip_device_is_torch():
     be, why = D.auto_backend(net)
     assert be == 'torch' and 'HIP' in why
     assert D.auto_backend(net, cnn_dtype='bf16')[0] == 'torch'
+
+
+def test_trained_dncnn_fixture_and_the_oracle_pair_loop_vs_the_unmodified_reference(golden_inputs):
+    """tests/golden/dncnn_25_trained.npz: KAIR's DnCNN-17 keys and shapes, a network that really denoises (the committed training record);
+    the oracle's DnCNN-pair loop (S6:485-525) driven by it on the CPU against the unmodified S6's output with the same weights at 5 iterations."""
+    from conftest import rel_l2, weights_trained
+    from oracle import admm_oracle as O
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    net, nlm, _ = D.build('dncnn_25')
+    net.load_state_dict(weights_trained('dncnn_25'), strict=True)
+    meta = json.load(open(os.path.join(GOLD, 'pnp_known.json')))
+    tr = meta['trained_dncnn']['training']['held_out_psnr']['25']
+    assert tr['denoised'] - tr['noisy'] >= 10.0
+    gold = np.load(os.path.join(GOLD, 'pnp50_set1_05.npz'))
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    y = O.synthesize(np.float32(golden_inputs['gray'] / 255.), mask, golden_inputs['noises'])
+    den = D.Denoiser('dncnn_25', net.eval(), nlm)
+
+    def denoise(a, i):
+        with torch.no_grad():
+            return den._one(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None], i)[0, 0].numpy()
+    o = meta['known50']['trained_cnc_dncnn_pair_it5_opts']
+    x = O.pnp_admm_cnc(y, mask, denoise, 5, o['alpha'], o['lambda1'], o['reo'], o['b'], denoise2=denoise)
+    assert rel_l2(x, gold['trained_cnc_dncnn_pair_it5']) <= 2e-6, rel_l2(x, gold['trained_cnc_dncnn_pair_it5'])

@@ -454,3 +454,31 @@ def test_the_default_cnn_backend_is_the_library_where_it_covers_the_network(env,
     assert any('cnn_backend=auto -> hip_f16x3' in r.getMessage() for r in caplog.records)
     expl, _ = S.PNP_ADMM_CNC_D('ffdnet_gray', mask, golden_inputs['noises'], cnn_backend='hip_f16x3', **kw)
     assert np.array_equal(dflt[0], expl[0])
+
+
+# ----------------------------------------------------------------------------------------------
+# Round 6: a TRAINED DnCNN-17 (tests/golden/dncnn_25_trained.npz, oracle/train_fixture_denoiser.py --model dncnn_25: 20.2 -> 32.0 dB at sigma = 25 on
+# held-out images) -- the x - n(x) family, 17 layers, trained weights instead of seeded ones -- under the unmodified scripts (oracle/
+# make_golden_pnp.py --trained-dncnn): PNP_ADMM_CNC_DnCNN at the S6:571 preset and PNP_ADMM_L1_D('dncnn_15') at the S3:341 preset, at the
+# iteration counts where float32 can hold the north star's bar.  All three CNN backends <= 1e-5; the f16x3 operand range check stays silent.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('n_it', [2, 5, 10])
+def test_pnp_with_a_trained_dncnn(env50, golden_inputs, backend, n_it, tmp_path, monkeypatch):
+    from conftest import weights_trained
+    sd = weights_trained('dncnn_25')
+    if backend == 'hip_f16x3' and n_it == 5:
+        monkeypatch.setenv('PNP_CONV_CHECK_RANGE', '1')             # every activation of the trained network stays inside the half range
+    mask = golden_inputs['masks']['Q_Random30'].astype(np.float64)
+    kw = dict(images=golden_inputs['gray'][None], results=str(tmp_path), cnn_backend=backend)
+    tag = 'trained_cnc_dncnn_pair_it%d' % n_it
+    opts = dict(env50['known50'][tag + '_opts'])
+    opts['iter_num'] = int(opts['iter_num'])
+    out, _ = env50['S'].PNP_ADMM_CNC_DnCNN('dncnn_25', 'dncnn_15', mask, golden_inputs['noises'], model=sd, **kw, **opts)
+    assert rel_l2(out[0], env50['gold50'][tag]) <= 1e-5, (tag, backend, rel_l2(out[0], env50['gold50'][tag]))
+    assert _psnr_close(out[0], env50['gold50'][tag], golden_inputs['gray'])
+    tag = 'trained_l1_d_dncnn_15_it%d' % n_it
+    opts = dict(env50['known50'][tag + '_opts'])
+    opts['iter_num'] = int(opts['iter_num'])
+    out = env50['S'].PNP_ADMM_L1_D('dncnn_15', mask, golden_inputs['noises'], model=sd, **kw, **opts)
+    assert rel_l2(out[0], env50['gold50'][tag]) <= 1e-5, (tag, backend, rel_l2(out[0], env50['gold50'][tag]))
