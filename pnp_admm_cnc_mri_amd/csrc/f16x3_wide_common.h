@@ -30,10 +30,17 @@ __device__ __forceinline__ WTilePos wtile_pos(const ConvArgs& a, int t) {
 // chunk u of helper thread h (0..255) is tile pixel p = wstage_pixel(h, u) = (row r, column c), channels 4 (h & 15) ..  Sixteen 16-lane groups:
 // the two groups of a 32-lane half take pixels 8 apart (8 x 272 bytes = 32 banks: their 8-byte LDS writes do not collide).
 __device__ __forceinline__ constexpr int wstage_pixel(int h, int u) { return ((h >> 4) >> 1) + 8 * ((h >> 4) & 1) + 16 * u; }
-// (the narrow kernel keeps one packed coordinate register per chunk; here the coordinates are recomputed per load -- a division by the
-// constant 18 is a multiplication, and a helper wave's vector instructions run beside its partner's MFMAs, not instead of them)
-struct WStaging { int h; int aW, pix; };
-__device__ __forceinline__ void wstaging_init(const ConvArgs& a, int h, WStaging& st, const int pix) { st.h = h; st.aW = a.W; st.pix = pix; }
+// One packed coordinate register per chunk, computed ONCE (the narrow kernel's StagingP): pk[u] = (r W + c) * pix | c -- pix is a multiple of 256,
+// the low byte holds the column, the only coordinate that needs a test per tile (rows fall out of the buffer range by themselves) -- or -1: no
+// such chunk.  A helper wave's vector instructions share the SIMD's issue port with its partner's MFMAs: fewer of them per load is time for those.
+struct WStaging { int pk[WT_XU]; };
+__device__ __forceinline__ void wstaging_init(const ConvArgs& a, int h, WStaging& st, const int pix) {
+#pragma unroll
+    for (int u = 0; u < WT_XU; ++u) {
+        const int p = wstage_pixel(h, u), r = p / WT_HX, c = p - r * WT_HX;
+        st.pk[u] = (p < WT_HY * WT_HX) ? (((r * a.W + c) * pix) | c) : -1;
+    }
+}
 struct WFetch { __amdgpu_buffer_rsrc_t rs; int origin, xlo, xhi; };
 __device__ __forceinline__ WFetch wfetch_begin(const ConvArgs& a, const WTilePos& q, int h, const int pix, const int coff, const bool any = true) {
     WFetch f;
@@ -47,9 +54,9 @@ template <int U0, int U1>
 __device__ __forceinline__ void wfetch_piece(const WFetch& f, const WStaging& st, f32x4 (&v)[WT_XU]) {
 #pragma unroll
     for (int u = U0; u < U1 && u < WT_XU; ++u) {
-        const int p = wstage_pixel(st.h, u), r = p / WT_HX, c = p - r * WT_HX;
-        const bool in = p < WT_HY * WT_HX && c >= f.xlo && c < f.xhi;
-        const int off = in ? f.origin + (r * st.aW + c) * st.pix : -16;
+        const int c = st.pk[u] & 255;
+        const bool in = st.pk[u] >= 0 && c >= f.xlo && c < f.xhi;
+        const int off = in ? f.origin + (st.pk[u] & ~255) : -16;
         const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(f.rs, off, 0, 0);
         v[u] = f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
     }

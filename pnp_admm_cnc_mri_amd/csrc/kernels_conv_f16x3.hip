@@ -582,11 +582,12 @@ hipError_t launch_conv3x3_f16x3(hipStream_t s, const float* x, const float* w, c
     const int cus = conv_compute_units();
     if (cus <= 0) return hipGetLastError();
     if (dilation == 1) {
-        // the wide kernel (kernels_conv_f16x3_wide.hip: 16 x 16 tiles, ONE workgroup per compute unit) once every workgroup has at least two
-        // items of its own -- below that the 8 x 16 tiles on two workgroups per unit spread a small layer better
+        // the wide kernel (kernels_conv_f16x3_wide.hip: 16 x 16 tiles, ONE workgroup per compute unit) once every compute unit has an item of
+        // its own -- below that the 8 x 16 tiles on two workgroups per unit spread a small layer better (one 256 x 256 slice at 64 channels:
+        // 17.1 us wide against 18.2 narrow; one 128 x 128 slice: 13.4 against 10.3, profiles/conv_f16x3_wide_probe_r06.txt)
         const long long items16 = (long long)n * ((W + 15) / 16) * ((H + 15) / 16) * (C >> 6);
         const int mode = conv_wide_mode();
-        if (mode >= 1 || (mode < 0 && items16 >= 2LL * cus)) return launch_conv3x3_f16x3_wide(s, x, w, bias, skip, y, n, C, H, W, relu, fmt);
+        if (mode >= 1 || (mode < 0 && items16 >= (long long)cus)) return launch_conv3x3_f16x3_wide(s, x, w, bias, skip, y, n, C, H, W, relu, fmt);
     }
     switch (dilation) {
         case 1: return launch_h3_dil<1>(s, a, items, cus);

@@ -16,6 +16,7 @@ plus the dispatch `denoising_step` (S6:18-67 == S3:19-68), the inference wrapper
 reference ships no weights: model_zoo/README.md).
 """
 import hashlib
+import os
 import logging
 import math
 
