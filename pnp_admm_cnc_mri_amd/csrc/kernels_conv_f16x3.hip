@@ -448,28 +448,36 @@ struct TailH3Args {
     // (2 y + dy, 2 x + dx) of the ONE-channel full-resolution result y [n][1][out_h][out_w] (pixel shuffle + the crop of the padded row / column)
     int shuffle, out_h, out_w;
 };
-__global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t) {
+__global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t, int ntiles) {
+    // PERSISTENT since round 6 (two workgroups per compute unit, tile = blockIdx.x + k gridDim.x): the next tile's input is requested into
+    // registers before this tile's matrix products and split into LDS behind them -- round 5's kernel was one workgroup per tile with nothing
+    // to overlap its fetch (130 us for 268 MB at 64 slices of 128 x 128: twice the memory time).
     constexpr int HX = Geo<1>::HX;
     __shared__ __attribute__((aligned(16))) float xin[Geo<1>::XIN];
     __shared__ __attribute__((aligned(16))) _Float16 wl[9 * 2 * 2 * 4 * 4 * 8];      // [tap][K step][hi, lo][kb][n < 4][8 halves]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kb = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;                                   // (uniform)
     ConvArgs a;                                                   // the staging helpers' view of the input
     a.x = t.x; a.H = t.H; a.W = t.W; a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y; a.fmt = 0;
-    const TilePos q = tile_pos(a, blockIdx.x);
     StagingP<1> st;
     staging_init_p<1>(a, tid, st, CV_C * 4);
     f32x4 xpre[Geo<1>::XU];
-    fetch_input_p<1>(a, q, st, xpre, tid, CV_C * 4, 0);
-    if (t.x2) {                                                   // uniform: x + x2, the sum never goes to memory (models/network_unet.py:134)
-        a.x = t.x2;
-        f32x4 x2pre[Geo<1>::XU];
-        fetch_input_p<1>(a, q, st, x2pre, tid, CV_C * 4, 0);
+    auto fetch = [&](const TilePos& q) __attribute__((always_inline)) {
+        a.x = t.x;
+        fetch_input_p<1>(a, q, st, xpre, tid, CV_C * 4, 0);
+        if (t.x2) {                                               // uniform: x + x2, the sum never goes to memory (models/network_unet.py:134)
+            a.x = t.x2;
+            f32x4 x2pre[Geo<1>::XU];
+            fetch_input_p<1>(a, q, st, x2pre, tid, CV_C * 4, 0);
 #pragma unroll
-        for (int u = 0; u < Geo<1>::XU; ++u) xpre[u] += x2pre[u];
-    }
-    // weights: w_oihw [cout][64][3][3] -> split halves in the B operand's order (columns >= cout are zeros the lanes supply themselves)
+            for (int u = 0; u < Geo<1>::XU; ++u) xpre[u] += x2pre[u];
+        }
+    };
+    fetch(tile_pos(a, tile));
+    // weights: w_oihw [cout][64][3][3] -> split halves in the B operand's order (columns >= cout are zeros the lanes supply themselves); once
     for (int e = tid; e < 9 * 2 * 4 * 4 * 8; e += CV_THREADS) {
         const int j = e & 7, n = (e >> 3) & 3, kq = (e >> 5) & 3, s2 = (e >> 7) & 1, tap = e >> 8;
         const float w = n < t.cout ? t.w[((size_t)n * 64 + 32 * s2 + 8 * kq + j) * 9 + tap] : 0.f;
@@ -478,66 +486,70 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_conv3x3_tail_h3(TailH3Args t)
         wl[base] = hi;
         wl[base + 4 * 32] = (_Float16)((w - (float)hi) * H3_SCALE);
     }
-    put_input_h3<1>(xin, tid, xpre);
-    __syncthreads();
-    f32x4 mainv[2], corrv[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) { mainv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; corrv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const char* const a0 = reinterpret_cast<const char*>(xin) + (2 * wv * HX + h3_row_pixel(i)) * (CV_PS * 4) + h3_chunk_pos(kb, 0, 0);
     const char* const b0 = reinterpret_cast<const char*>(wl) + kb * 64 + (i & 3) * 16;
     const bool col = i < t.cout;
     const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float b = (col && t.bias) ? t.bias[i] : 0.f;
+#pragma unroll 1
+    for (; tile < ntiles; tile += gridDim.x) {
+        const TilePos q = tile_pos(a, tile);
+        put_input_h3<1>(xin, tid, xpre);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile_pos(a, tile + gridDim.x));       // in flight behind this tile's matrix products
+        f32x4 mainv[2], corrv[2];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const char* ap = a0 + (ky * HX + kx) * (CV_PS * 4);
+        for (int mt = 0; mt < 2; ++mt) { mainv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; corrv[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            h8 bh = *reinterpret_cast<const h8*>(b0 + ((tap * 2 + s2) * 2) * 256);
-            h8 bl = *reinterpret_cast<const h8*>(b0 + ((tap * 2 + s2) * 2 + 1) * 256);
-            bh = col ? bh : zero; bl = col ? bl : zero;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const char* ap = a0 + (ky * HX + kx) * (CV_PS * 4);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const h8 ah = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 32 * s2);
-                const h8 al = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 32 * s2 + 16);
-                mainv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, mainv[mt], 0, 0, 0);
-                corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, corrv[mt], 0, 0, 0);
-                corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, corrv[mt], 0, 0, 0);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h8 bh = *reinterpret_cast<const h8*>(b0 + ((tap * 2 + s2) * 2) * 256);
+                h8 bl = *reinterpret_cast<const h8*>(b0 + ((tap * 2 + s2) * 2 + 1) * 256);
+                bh = col ? bh : zero; bl = col ? bl : zero;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const h8 ah = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 32 * s2);
+                    const h8 al = *reinterpret_cast<const h8*>(ap + mt * (HX * CV_PS * 4) + 32 * s2 + 16);
+                    mainv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, mainv[mt], 0, 0, 0);
+                    corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, corrv[mt], 0, 0, 0);
+                    corrv[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, corrv[mt], 0, 0, 0);
+                }
             }
         }
-    }
-    // accumulator (reg r, lane (i, kb)) of M tile mt = pixel (tile row 2 w + mt, column h3_row_pixel(4 kb + r)), output channel i
-    const float b = (col && t.bias) ? t.bias[i] : 0.f;
-    if (t.shuffle) {
-        // FFDNet: the tile's 8 x 16 x 4 values are a 16 x 32 block of the full-resolution result; it is assembled in LDS (the input tile is
-        // no longer needed once every wave is past its taps) and leaves as whole rows, two consecutive pixels per thread
-        __syncthreads();
-        if (col) {
+        // accumulator (reg r, lane (i, kb)) of M tile mt = pixel (tile row 2 w + mt, column h3_row_pixel(4 kb + r)), output channel i
+        __syncthreads();                                          // every wave is past its taps: the tile may be reused (below, or by the next tile)
+        if (t.shuffle) {
+            // FFDNet: the tile's 8 x 16 x 4 values are a 16 x 32 block of the full-resolution result; it is assembled in LDS and leaves as
+            // whole rows, two consecutive pixels per thread
+            if (col) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xin[(2 * (2 * wv + mt) + (i >> 1)) * 32 + 2 * (h3_row_pixel(4 * kb) + r) + (i & 1)] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
-        }
-        __syncthreads();
-        const int orow = tid >> 4, ocol = 2 * (tid & 15), oy = 2 * q.y0 + orow, ox = 2 * q.x0 + ocol;
-        if (oy < t.out_h) {
-            float* dst = t.y + ((size_t)q.img * t.out_h + oy) * t.out_w + ox;
-            if (ox < t.out_w) dst[0] = xin[orow * 32 + ocol];
-            if (ox + 1 < t.out_w) dst[1] = xin[orow * 32 + ocol + 1];
-        }
-        return;
-    }
-    if (col) {
-        const size_t plane = (size_t)t.H * t.W;
+                    for (int r = 0; r < 4; ++r)
+                        xin[(2 * (2 * wv + mt) + (i >> 1)) * 32 + 2 * (h3_row_pixel(4 * kb) + r) + (i & 1)] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+            }
+            __syncthreads();
+            const int orow = tid >> 4, ocol = 2 * (tid & 15), oy = 2 * q.y0 + orow, ox = 2 * q.x0 + ocol;
+            if (oy < t.out_h) {
+                float* dst = t.y + ((size_t)q.img * t.out_h + oy) * t.out_w + ox;
+                if (ox < t.out_w) dst[0] = xin[orow * 32 + ocol];
+                if (ox + 1 < t.out_w) dst[1] = xin[orow * 32 + ocol + 1];
+            }
+            __syncthreads();                                      // the assembled block is read: the next tile may be written
+        } else if (col) {
+            const size_t plane = (size_t)t.H * t.W;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int gy = q.y0 + 2 * wv + mt;
+            for (int mt = 0; mt < 2; ++mt) {
+                const int gy = q.y0 + 2 * wv + mt;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gx = q.x0 + h3_row_pixel(4 * kb) + r;
-                if (gy < t.H && gx < t.W)
-                    t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+                for (int r = 0; r < 4; ++r) {
+                    const int gx = q.x0 + h3_row_pixel(4 * kb) + r;
+                    if (gy < t.H && gx < t.W)
+                        t.y[((size_t)q.img * t.cout + i) * plane + (size_t)gy * t.W + gx] = fmaf(corrv[mt][r], H3_RSCALE, mainv[mt][r]) + b;
+                }
             }
         }
     }
@@ -553,7 +565,10 @@ hipError_t launch_conv3x3_tail_f16x3(hipStream_t s, const float* x_nhwc, const f
     t.tiles_x = (W + CV_TX - 1) / CV_TX; t.tiles_y = (H + CV_TY - 1) / CV_TY;
     const long long tiles = (long long)n * t.tiles_x * t.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_conv3x3_tail_h3, dim3((unsigned)tiles), dim3(CV_THREADS), 0, s, t);
+    const int cus = conv_compute_units();
+    if (cus <= 0) return hipGetLastError();
+    const long long grid = tiles < 2LL * cus ? tiles : 2LL * cus;          // persistent, two workgroups per compute unit; every loop ends: tile < ntiles
+    hipLaunchKernelGGL(k_conv3x3_tail_h3, dim3((unsigned)grid), dim3(CV_THREADS), 0, s, t, (int)tiles);
     return hipGetLastError();
 }
 
