@@ -59,6 +59,7 @@ __device__ __forceinline__ void wepilogue(const ConvArgs& a, const WTilePos& q, 
 #ifdef WT_ABL_NOST                                                // timing-only ablation: the values are computed, no store is issued
 #define WT_STORE(o_, off_) asm volatile("" :: "v"(o_))
 #else
+// (cache-policy bits on these stores -- sc0, nt, both -- measured within +-1 % of none: profiles/experiments/ab_store_cache_policy_wide_r06.txt)
 #define WT_STORE(o_, off_) __builtin_amdgcn_raw_buffer_store_b128(o_, ry, off_, 0, 0)
 #endif
     f32x4 bs[2][2];                                              // [g][e]: this lane's biases, from LDS (the helpers put them there)
