@@ -62,7 +62,7 @@ def main():
     ap.add_argument('--size', type=int, default=256, choices=[256, 512], help='512 = the shape of config 5 (seeded mask bank of 3)')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--cnn-batch', type=int, default=64)
+    ap.add_argument('--cnn-batch', type=int, default=None, help='slices per CNN call (default: the Denoiser\'s: 64, 256 for the plain stacks on the HIP backends)')
     ap.add_argument('--mask', default=None)
     ap.add_argument('--cnn-dtype', default=None, choices=[None, 'bf16', 'fp16'], help='autocast throughput mode, off parity')
     ap.add_argument('--cnn-backend', default='torch', choices=['torch', 'hip', 'hip_f16x3', 'auto'],
@@ -131,6 +131,7 @@ def main():
     den = D.Denoiser(args.model, net.eval(), nlm, sigmas=sig, noises=noise[0], bank=bank, cnn_batch=args.cnn_batch, cnn_dtype=args.cnn_dtype,
                      backend=args.cnn_backend, graph=args.cnn_graph).to(dev)
     args.cnn_backend = den.backend                      # 'auto' resolved (denoisers.auto_backend)
+    args.cnn_batch = den.cnn_batch                      # None resolved
     flop_per_call, flop_f16x3_part = D.forward_flops(den, H, W, dev, detail=True)     # one slice, one D(.)
 
     eng = P.Engine(H, W, Bmax=B, device=local_rank)

@@ -788,7 +788,7 @@ class Denoiser:
     [B,1,H,W] float32 CUDA tensor to the denoised tensor for iteration i."""
 
     def __init__(self, model_name, model, noise_level_model, sigmas=None, noises=None, x8=False, bank=None,
-                 cnn_batch=64, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch', graph=False):
+                 cnn_batch=None, channels_last=True, cnn_dtype=None, miopen_find='auto', backend='torch', graph=False):
         """backend: 'torch' (default: the whole forward in PyTorch-ROCm / MIOpen, as the north star keeps it) or 'hip' (the
         64 -> 64 conv3x3 (+ ReLU) layers of DnCNN / FDnCNN / FFDNet / IRCNN (dilations 1..4) and DRUNet's 64-channel residual
         blocks on libpnpmri.so's fp32-MFMA kernel, the plain stacks' first and last layers on its direct kernels; float32 only)
@@ -822,6 +822,14 @@ class Denoiser:
         self.x8 = x8
         self.bank = bank                  # ircnn: {str(idx): state_dict}
         self.former_idx = 0
+        # slices per CNN call.  None (default): 64 -- except for the plain stacks (FFDNet, DnCNN, FDnCNN, IRCNN) on the HIP backends, where a call
+        # takes up to 256 slices of 256 x 256 (fewer for larger slices: the same pixel count): their 64-channel layers are short launches at
+        # 64 slices (16 items per workgroup of the wide kernel), and 256 per call measured +5 % on config 3 (profiles/experiments/
+        # ab_cnn_batch_r06.txt; DRUNet: +-0, its tensors are four times larger).  Results do not depend on it (bit-equal per slice on the HIP
+        # backends, tests/test_gpu_round2.py).
+        self._cnn_batch_auto = cnn_batch is None
+        if cnn_batch is None:
+            cnn_batch = 256 if (backend in HIP_BACKENDS and isinstance(model, _PlainStack)) else 64
         self.cnn_batch = cnn_batch
         self.channels_last = channels_last        # NHWC weights/activations: MIOpen's faster fp32 conv path (+9 %)
         # MIOpen "find" mode (torch.backends.cudnn.benchmark) for the forward passes.  Without a find-db entry MIOpen's
@@ -942,15 +950,18 @@ class Denoiser:
         before = cd.benchmark
         cd.benchmark = bool(find or before)
         try:
-            for b0 in range(0, B, self.cnn_batch):
+            cb = self.cnn_batch
+            if self._cnn_batch_auto and cb > 64:          # the automatic 256 is for 256 x 256 slices: the same pixel count per call for larger ones
+                cb = max(64, cb * 65536 // max(65536, x.shape[-2] * x.shape[-1]))
+            for b0 in range(0, B, cb):
                 if (self.cnn_dtype is None and self.backend == 'hip_f16x3' and isinstance(self.model, FFDNet) and x.is_cuda and out.is_contiguous()
                         and out.dtype == torch.float32 and out.device == x.device):
-                    self._one(x[b0:b0 + self.cnn_batch], i, out=out[b0:b0 + self.cnn_batch])     # no copy: the last layer writes the slice itself
+                    self._one(x[b0:b0 + cb], i, out=out[b0:b0 + cb])     # no copy: the last layer writes the slice itself
                 elif self.cnn_dtype is None:
-                    out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i)
+                    out[b0:b0 + cb] = self._one(x[b0:b0 + cb], i)
                 else:
                     with torch.autocast('cuda', dtype=self.cnn_dtype):
-                        out[b0:b0 + self.cnn_batch] = self._one(x[b0:b0 + self.cnn_batch], i).float()
+                        out[b0:b0 + cb] = self._one(x[b0:b0 + cb], i).float()
         finally:
             cd.benchmark = before
         return out

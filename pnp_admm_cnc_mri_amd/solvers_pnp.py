@@ -14,7 +14,8 @@ Extra keyword arguments (all optional): images=, y=, mask_id=, testsets=, testse
 save_E=, device=, return_info=  as in solvers.py, plus
     model_zoo='model_zoo'   directory of KAIR .pth files (S6:107-109)
     model= / model2=        an nn.Module (or state_dict) instead of a file
-    cnn_batch=64            slices per CNN forward (activation memory)
+    cnn_batch=None          slices per CNN forward (activation memory).  None: 64 -- 256 (of 256 x 256; the same pixel count for larger slices) for
+                            the plain stacks on the HIP backends, whose layers are short launches at 64 (denoisers.Denoiser)
     cnn_dtype=None          None = float32 (parity); 'bf16'/'fp16' = autocast throughput mode, off parity
     miopen_find='auto'      'auto': torch.backends.cudnn.benchmark is switched on around the CNN forward passes of conv batches
                             of >= 16 images and restored afterwards (a process-global flag: INTEGRATION.md section 4);
@@ -122,7 +123,7 @@ def _finish_pnp(torch, job, eng, x, extra, return_device=False):
 
 def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                    testset_name='Set1', results='results', save_E=None, device=None, return_info=False,
-                   model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False,
+                   model_zoo='model_zoo', model=None, cnn_batch=None, cnn_dtype=None, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False,
                    state0=None, iter_start=0, **PNP_ADMM_CNC_D_opts):
     """CNC ADMM with a CNN denoiser in place of both soft-thresholds.  Reference: S6:79-351."""
     import torch
@@ -160,7 +161,7 @@ def PNP_ADMM_CNC_D(model_name, mask, noises, images=None, y=None, mask_id=None, 
 
 def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=None, mask_id=None,
                        testsets='testsets', testset_name='Set1', results='results', save_E=None, device=None,
-                       return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=64,
+                       return_info=False, model_zoo='model_zoo', model=None, model2=None, cnn_batch=None,
                        cnn_dtype=None, faithful_model2_path=True, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False, **opts):
     """Two DnCNN-17 nets: s = D1(z), z = D2(t).  Reference: S6:372-567.
     `faithful_model2_path`: the reference loads model_path1 into BOTH nets (S6:435) although it logs
@@ -198,7 +199,7 @@ def PNP_ADMM_CNC_DnCNN(model_name1, model_name2, mask, noises, images=None, y=No
 
 def PNP_ADMM_L1_D(model_name, mask, noises, images=None, y=None, mask_id=None, testsets='testsets',
                   testset_name='Set1', results='results', save_E=None, device=None, return_info=False,
-                  model_zoo='model_zoo', model=None, cnn_batch=64, cnn_dtype=None, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False,
+                  model_zoo='model_zoo', model=None, cnn_batch=None, cnn_dtype=None, miopen_find='auto', cnn_backend='auto', cnn_graph=False, return_device=False,
                   state0=None, iter_start=0, **PNP_ADMM_L1_D_opts):
     """L1-ADMM with the CNN as the prox: z = D(x + w).  Reference: S3:77-337."""
     import torch
